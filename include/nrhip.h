@@ -1,0 +1,207 @@
+/* libnrhip — C ABI of the MI355X (gfx950) NRMS / NAML encoder + scorer hot path.
+ *
+ * The reference (patngnw/NewsRecommendation) is pure Python on ATen ops and has no FFI of
+ * its own; each entry point below replaces one ATen op sequence of the reference's
+ * src/model/{NRMS,NAML,model_utils}.py and is what a `ctypes` binding inside those modules would call
+ * (INTEGRATION.md shows the stub).  Citations are paths under /root/reference/.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers unless a comment says host.  Row-major, contiguous
+ *    unless a leading dimension (`ld*`, in elements) is given.
+ *  - `dtype` selects the storage type of activations / packed weights AND the MFMA operand
+ *    type: NR_F32 (v_mfma_f32_16x16x4_f32, exact fp32) or NR_BF16 (v_mfma_f32_16x16x32_bf16,
+ *    fp32 accumulate).  Parameters, gradients of parameters, pooled vectors, scores and the
+ *    loss are always fp32.
+ *  - The caller owns every buffer (outputs, saved activations, workspaces).  The library
+ *    never allocates or frees device memory and never synchronises the stream; every call
+ *    only enqueues kernels on `stream` (a hipStream_t).
+ *  - Returns NR_OK (0) or an NR_ERR_* code; nr_last_error() gives the message.  Nothing
+ *    throws across the ABI.
+ *  - Leading dimensions of dtype buffers used as GEMM operands must be multiples of one
+ *    16-byte chunk (4 fp32 / 8 bf16) and the buffers 16-byte aligned; nr_cast_pad produces
+ *    such buffers (zero padded).
+ *  - "accumulate" outputs (dw*, db*, dtable, dpad) are ADDED to: zero them first.
+ *  - Dropout: Bernoulli keep decisions are a pure function of (seed, element index); the
+ *    backward call must receive the same seed.  p == 0 disables it (eval mode).
+ */
+#ifndef NRHIP_H
+#define NRHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NR_F32 0
+#define NR_BF16 1
+
+#define NR_OK 0
+#define NR_ERR_ARG 1
+#define NR_ERR_HIP 2
+
+#define NR_SRC_DENSE 0  /* x is [M, ldx] of dtype                                   */
+#define NR_SRC_GATHER 1 /* x is a table [V, ldx] of dtype, row m = table[ids[m*ids_stride]] */
+
+typedef void* nr_stream_t; /* hipStream_t */
+
+int nr_version(void);
+/* Copies the calling thread's last error message (NUL terminated) into buf; returns its length. */
+int nr_last_error(char* buf, size_t n);
+
+/* ---------------------------------------------------------------------------------------
+ * Packing: fp32 master parameter -> dtype operand with zero padded leading dimension.
+ * transpose == 0: dst[r, c] = src[r, c]      dst is [rows, ld_dst]
+ * transpose == 1: dst[c, r] = src[r, c]      dst is [cols, ld_dst]
+ * Replaces the implicit `.float()` / `.cuda()` parameter materialisation of
+ * src/model/NRMS.py:70-73 and src/main.py:79.                                              */
+int nr_cast_pad(const float* src, int rows, int cols, int ld_src, void* dst, int ld_dst, int dtype,
+                int transpose, nr_stream_t stream);
+/* Conv1d weight [N, D, 3] (src/model/NAML.py:27-32) -> tap-major GEMM operand [N, 3*Dp]
+ * (dst[n, tap*Dp + d] = w[n, d, tap]); unpack is the inverse on an fp32 gradient.          */
+int nr_pack_conv_w(const float* w, int N, int D, void* dst, int Dp, int dtype, nr_stream_t stream);
+int nr_unpack_conv_dw(const float* dw_pack, int N, int D, int Dp, float* dw, nr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K1  embedding row gather — nn.Embedding(padding_idx=0) lookup,
+ * src/model/NRMS.py:28, src/model/NAML.py:48-50, and the eval-time news-vector gather
+ * src/dataset.py:68,72.  out[m, 0:cols] = table[ids[m*ids_stride], 0:cols] (fp32 out).
+ * bwd: dtable[ids[m], :] += dout[m, :] for ids[m] != 0 (padding_idx row gets no gradient). */
+int nr_embed_gather_fwd(const void* table, int ld_table, int dtype, const int32_t* ids, int n_ids,
+                        int ids_stride, int cols, float* out, int ld_out, nr_stream_t stream);
+int nr_embed_gather_bwd(const float* dout, int ld_dout, const int32_t* ids, int n_ids, int ids_stride,
+                        int cols, float* dtable, int ld_dtable, nr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K3 (+K1,K2 fused)  multi-head self-attention — MultiHeadSelfAttention.forward +
+ * ScaledDotProductAttention.forward, src/model/model_utils.py:39-55,78-95, with the
+ * embedding lookup and the two F.dropout calls of src/model/NRMS.py:28-34 folded in.
+ *   X      = dropout_in(rows of x)                         [n*L, d_model]
+ *   Q|K|V  = X W_{Q|K|V}^T + b                             [n*L, 3N], N = heads*d_head
+ *   per head: A = exp(QK^T/sqrt(d)) * mask_j / (sum_j + 1e-8);  ctx = A V
+ *   y      = dropout_out(concat_heads ctx)                 [n*L, N]
+ * No max-subtraction in the reference; the kernels use the algebraically identical stable
+ * form exp(s-m)/(sum exp(s-m) + 1e-8 exp(-m)).                                             */
+typedef struct {
+  int n, L, d_model, heads, d_head, dtype;
+  int src_kind;       /* NR_SRC_DENSE | NR_SRC_GATHER */
+  const void* x;      /* dense: [n*L, ldx] dtype; gather: table [V, ldx] dtype */
+  int ldx;
+  const int32_t* ids; /* gather: [n*L] token ids (int32, as src/preprocess.py:52-54)        */
+  float p_in;         /* dropout on X (src/model/NRMS.py:28-30); element index m*d_model + k */
+  uint32_t seed_in;
+  float p_out;        /* dropout on y (src/model/NRMS.py:32-34); element index m*N + c       */
+  uint32_t seed_out;
+  const float* mask;  /* [n, L] key-side 0/1 mask or NULL (src/model/model_utils.py:50-51)   */
+  const void* w_qkv;  /* [3N, ldw] dtype: rows W_Q | W_K | W_V (nr_cast_pad of each)         */
+  int ldw;
+  const float* b_qkv; /* [3N] fp32 */
+} nr_mhsa_desc;
+
+/* qkv: [n*L, 3N] dtype (saved for backward); y: [n*L, N] dtype. */
+int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream);
+/* dy [n*L, N] dtype.  dqkv: workspace [n*L, 3N] dtype.  w_qkv_t: [Kp, ldwt] dtype = w_qkv^T
+ * (nr_cast_pad transpose=1; Kp = d_model rounded up to a chunk; needed only if dx/dtable).
+ * dw_qkv [3N, d_model], db_qkv [3N]: fp32, accumulated.  dx: dense source -> [n*L, ldx] dtype
+ * or NULL; dtable: gather source -> [V, d_model] fp32 accumulated (skips id 0) or NULL.      */
+int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dqkv, const void* w_qkv_t,
+                int ldwt, float* dw_qkv, float* db_qkv, void* dx, float* dtable, nr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K4 (+K1,K2 fused)  Conv1d(D, N, kernel_size=3, padding=1) over title tokens,
+ * src/model/NAML.py:27-32,47-54: row gather of a [T*D] title-embedding row per news id,
+ * dropout, im2col-free GEMM against the tap-major packed weight.  y [n*T, N] dtype.         */
+typedef struct {
+  int n, T, D, Dp, N, dtype;
+  const void* table;  /* [V, T*Dp] dtype (nr_cast_pad of the [V*T, D] view with ld_dst = Dp) */
+  const int32_t* ids; /* news ids, id of row i = ids[i*ids_stride] (src/model/NAML.py:47)    */
+  int ids_stride;
+  float p_in;         /* dropout on the gathered [T, D] block (src/model/NAML.py:51-53); element index (i*T+t)*D + d */
+  uint32_t seed_in;
+  const void* w_pack; /* [N, 3*Dp] dtype (nr_pack_conv_w) */
+  const float* bias;  /* [N] */
+} nr_conv_desc;
+int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream);
+/* dw_pack [N, 3*Dp] fp32 accumulated (nr_unpack_conv_dw -> [N, D, 3]); db [N] accumulated.
+ * The title-embedding table is frozen on this path (src/demo.sh:12): no dtable.             */
+int nr_conv1d_k3_bwd(const nr_conv_desc* d, const void* dy, float* dw_pack, float* db, nr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K5  additive attention pooling — AttentionPooling.forward, src/model/model_utils.py:13-31
+ *   e = tanh(x W1^T + b1); a = exp(e w2 + b2) * mask; a /= sum_L a + 1e-8; out = sum_L a x   */
+typedef struct {
+  int n, L, N, q, dtype;
+  const void* x;     /* [n*L, N] dtype */
+  const float* mask; /* [n, L] or NULL */
+  const void* w1;    /* [q, ldw1] dtype */
+  int ldw1;
+  const float* b1;   /* [q] */
+  const float* w2;   /* [q] (att_fc2.weight [1, q]) */
+  const float* b2;   /* [1] */
+} nr_pool_desc;
+/* e: [n*L, q] dtype (tanh output, saved); alpha: [n*L] fp32 (saved); out: fp32, row i at out + i*ld_out. */
+int nr_additive_pool_fwd(const nr_pool_desc* d, void* e, float* alpha, float* out, int ld_out, nr_stream_t stream);
+/* g: fp32 d(out), row i at g + i*ld_g.  w1_t [N, ldw1t] dtype = w1^T.  dpre: workspace [n*L, q] dtype.
+ * partial: workspace fp32 [ceil(n/8) * (q+1)].  dw1 [q,N], db1 [q], dw2 [q], db2 [1]: accumulated.
+ * dx: [n*L, N] dtype (overwritten) or NULL.                                                  */
+int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alpha, const float* g, int ld_g,
+                         const void* w1_t, int ldw1t, void* dpre, float* partial, float* dw1, float* db1,
+                         float* dw2, float* db2, void* dx, nr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K6  pad-doc blend — src/model/NRMS.py:59-60, src/model/NAML.py:94-95:
+ *   out = x*m + pad*(1-m), written as dtype (the GEMM operand of the user-level ops).
+ * mask == NULL: plain fp32 -> dtype cast (user_log_mask=True path).
+ * bwd: dx = dout*m (fp32); dpad[c] += sum (1-m) dout (accumulated).                          */
+int nr_pad_blend_fwd(const float* x, const float* mask, const float* pad, void* out, int n, int L, int N,
+                     int dtype, nr_stream_t stream);
+int nr_pad_blend_bwd(const void* dout, const float* mask, float* dx, float* dpad, int n, int L, int N,
+                     int dtype, nr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K7  gather + Linear — category / subcategory view, src/model/NAML.py:19-24,60-68:
+ *   out[m, :] = rows(x)[m, :] W^T + b      (fp32 out, row m at out + m*ld_out)               */
+typedef struct {
+  int M, K, N, dtype;
+  int src_kind;
+  const void* x; /* dense [M, ldx] dtype or table [V, ldx] dtype */
+  int ldx;
+  const int32_t* ids;
+  int ids_stride;
+  const void* w; /* [N, ldw] dtype */
+  int ldw;
+  const float* bias; /* [N] or NULL */
+  const void* w_t;   /* [K, ldwt] dtype = w^T; only read by nr_linear_bwd when dtable != NULL */
+  int ldwt;
+} nr_linear_desc;
+int nr_linear_fwd(const nr_linear_desc* d, float* out, int ld_out, nr_stream_t stream);
+/* dout fp32 (row stride ld_dout); dout_ws: workspace [M, Nc] dtype, Nc = N rounded up to a chunk.
+ * dw [N, K], db [N] accumulated; dtable [V, K] fp32 accumulated (gather source, skips id 0) or NULL. */
+int nr_linear_bwd(const nr_linear_desc* d, const float* dout, int ld_dout, void* dout_ws, float* dw,
+                  float* db, float* dtable, nr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K8  candidate scorer + cross-entropy — torch.bmm + nn.CrossEntropyLoss,
+ * src/model/NRMS.py:77,93-94, src/model/NAML.py:111,128-129.
+ *   score[b, j] = <cand[b, j, :], user[b, :]>;  loss = mean_b -log softmax(score[b])[label[b]]
+ * cand row (b, j) at cand + (b*C + j)*ld_cand.  lossvec: workspace fp32 [B].                 */
+int nr_score_ce_fwd(const float* cand, int ld_cand, const float* user, const int64_t* label, float* score,
+                    float* loss, float* lossvec, int B, int C, int N, nr_stream_t stream);
+/* gloss: DEVICE pointer to the scalar d(loss) (no host sync); gscore: optional [B, C] d(score) added to
+ * the cross-entropy term, or NULL.  dcand row (b, j) at dcand + (b*C + j)*ld_dcand; duser [B, N].        */
+int nr_score_ce_bwd(const float* cand, int ld_cand, const float* user, const int64_t* label,
+                    const float* score, const float* gloss, const float* gscore, float* dcand, int ld_dcand,
+                    float* duser, int B, int C, int N, nr_stream_t stream);
+/* Eval-time scorer (src/main.py:253): variable-length candidate lists.
+ * score[i] = <news_vecs[cand_ids[i]], user[imp_of[i]]>, i in [0, n_cand).                     */
+int nr_score_eval(const float* news_vecs, int ld_news, const int32_t* cand_ids, const int32_t* imp_of,
+                  const float* user, int ld_user, float* score, int n_cand, int N, nr_stream_t stream);
+
+/* Test hook: materialise the dropout keep mask (1.0 / 0.0) for `count` element indices. */
+int nr_dropout_mask(float* out, uint32_t count, float p, uint32_t seed, nr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRHIP_H */

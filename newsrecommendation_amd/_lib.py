@@ -1,0 +1,132 @@
+"""ctypes binding of libnrhip.so (the C ABI declared in include/nrhip.h).
+
+The product path has NO fallback: if the shared library is missing, or a call fails, a
+RuntimeError is raised.  Nothing here imports `oracle/`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+NR_F32, NR_BF16 = 0, 1
+NR_SRC_DENSE, NR_SRC_GATHER = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnrhip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_i64p = C.POINTER(C.c_int64)
+
+
+class MhsaDesc(C.Structure):
+    _fields_ = [("n", C.c_int), ("L", C.c_int), ("d_model", C.c_int), ("heads", C.c_int), ("d_head", C.c_int),
+                ("dtype", C.c_int), ("src_kind", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int), ("ids", C.c_void_p),
+                ("p_in", C.c_float), ("seed_in", C.c_uint32), ("p_out", C.c_float), ("seed_out", C.c_uint32),
+                ("mask", C.c_void_p), ("w_qkv", C.c_void_p), ("ldw", C.c_int), ("b_qkv", C.c_void_p)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("n", C.c_int), ("T", C.c_int), ("D", C.c_int), ("Dp", C.c_int), ("N", C.c_int), ("dtype", C.c_int),
+                ("table", C.c_void_p), ("ids", C.c_void_p), ("ids_stride", C.c_int), ("p_in", C.c_float),
+                ("seed_in", C.c_uint32), ("w_pack", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [("n", C.c_int), ("L", C.c_int), ("N", C.c_int), ("q", C.c_int), ("dtype", C.c_int), ("x", C.c_void_p),
+                ("mask", C.c_void_p), ("w1", C.c_void_p), ("ldw1", C.c_int), ("b1", C.c_void_p), ("w2", C.c_void_p),
+                ("b2", C.c_void_p)]
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [("M", C.c_int), ("K", C.c_int), ("N", C.c_int), ("dtype", C.c_int), ("src_kind", C.c_int),
+                ("x", C.c_void_p), ("ldx", C.c_int), ("ids", C.c_void_p), ("ids_stride", C.c_int), ("w", C.c_void_p),
+                ("ldw", C.c_int), ("bias", C.c_void_p), ("w_t", C.c_void_p), ("ldwt", C.c_int)]
+
+
+_vp, _i, _f, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_uint32
+# name -> argtypes ; every entry returns int.  Must list exactly the symbols of include/nrhip.h.
+SIGNATURES = {
+    "nr_version": [],
+    "nr_last_error": [C.c_char_p, C.c_size_t],
+    "nr_cast_pad": [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp],
+    "nr_pack_conv_w": [_vp, _i, _i, _vp, _i, _i, _vp],
+    "nr_unpack_conv_dw": [_vp, _i, _i, _i, _vp, _vp],
+    "nr_embed_gather_fwd": [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp],
+    "nr_embed_gather_bwd": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp],
+    "nr_mhsa_fwd": [C.POINTER(MhsaDesc), _vp, _vp, _vp],
+    "nr_mhsa_bwd": [C.POINTER(MhsaDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "nr_conv1d_k3_fwd": [C.POINTER(ConvDesc), _vp, _vp],
+    "nr_conv1d_k3_bwd": [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp],
+    "nr_additive_pool_fwd": [C.POINTER(PoolDesc), _vp, _vp, _vp, _i, _vp],
+    "nr_additive_pool_bwd": [C.POINTER(PoolDesc), _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "nr_pad_blend_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "nr_pad_blend_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "nr_linear_fwd": [C.POINTER(LinearDesc), _vp, _i, _vp],
+    "nr_linear_bwd": [C.POINTER(LinearDesc), _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "nr_score_ce_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "nr_score_ce_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
+    "nr_score_eval": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
+    "nr_dropout_mask": [_vp, _u32, _f, _u32, _vp],
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build(force: bool = False) -> str:
+    """Compile libnrhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.run(["make", "-C", CSRC_DIR, "-j4"], check=True)
+    elif _stale():
+        subprocess.run(["make", "-C", CSRC_DIR, "-j4"], check=True)
+    return LIB_PATH
+
+
+def _stale() -> bool:
+    try:
+        t = os.path.getmtime(LIB_PATH)
+        srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".h"))]
+        srcs.append(os.path.join(os.path.dirname(_HERE), "include", "nrhip.h"))
+        return any(os.path.getmtime(s) > t for s in srcs)
+    except OSError:
+        return False
+
+
+def lib():
+    """The loaded library; raises RuntimeError if it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"libnrhip.so not found at {LIB_PATH}: build it with "
+                        "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C newsrecommendation_amd/csrc`. "
+                        "newsrecommendation_amd has no CPU fallback.")
+                L = C.CDLL(LIB_PATH)
+                for name, argtypes in SIGNATURES.items():
+                    fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+                    fn.argtypes = argtypes
+                    fn.restype = C.c_int
+                _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    lib().nr_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"libnrhip {what} failed (code {rc}): {last_error()}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,277 @@
+// extern "C" entry points of libnrhip that compose several launches (see include/nrhip.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "nr_gemm.h"
+
+// launchers defined in nr_attn.hip / nr_pool.hip
+int nr_launch_attn(bool bwd, int dtype, const void* qkv, const float* mask, void* y, const void* dy, void* dqkv, int n, int L,
+                   int heads, int d_head, const DropCfg& drop, hipStream_t stream);
+int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
+                            float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s);
+int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float* w2, const float* alpha, const float* g,
+                            int ld_g, void* dpre, float* partial, float* dw2, float* db2, int n, int L, int N, int q,
+                            hipStream_t s);
+int nr_launch_cast_rows(int dtype, const float* src, int ld_src, void* dst, int ld_dst, int rows, int cols, hipStream_t s);
+
+static thread_local char g_err[512] = "";
+
+void nr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline bool dtype_ok(int dt) { return dt == NR_F32 || dt == NR_BF16; }
+
+static RowSrc dense_rows(const void* base, int ld, int cols) {
+  RowSrc s;
+  memset(&s, 0, sizeof(s));
+  s.base = base; s.ld = ld; s.kind = ROWS_DENSE; s.ids_stride = 1; s.Tlen = 1; s.Dtrue = cols;
+  s.drop = nr_make_drop(0.f, 0);
+  return s;
+}
+
+static EpiArgs store_epi(void* C, int ldc, int out_dtype, const float* bias, int act_tanh) {
+  EpiArgs e;
+  memset(&e, 0, sizeof(e));
+  e.C = C; e.ldc = ldc; e.out_dtype = out_dtype; e.bias = bias; e.act_tanh = act_tanh;
+  e.drop = nr_make_drop(0.f, 0);
+  return e;
+}
+
+static int mhsa_rows(const nr_mhsa_desc* d, RowSrc* out) {
+  RowSrc s = dense_rows(d->x, d->ldx, d->d_model);
+  if (d->src_kind == NR_SRC_GATHER) {
+    NR_CHECK_ARG(d->ids != nullptr, "mhsa: gather source without ids");
+    s.kind = ROWS_GATHER;
+    s.ids = d->ids;
+  } else {
+    NR_CHECK_ARG(d->src_kind == NR_SRC_DENSE, "mhsa: bad src_kind %d", d->src_kind);
+  }
+  s.drop = nr_make_drop(d->p_in, d->seed_in);
+  *out = s;
+  return NR_OK;
+}
+
+static int mhsa_check(const nr_mhsa_desc* d) {
+  NR_CHECK_ARG(d != nullptr, "mhsa: null descriptor");
+  NR_CHECK_ARG(dtype_ok(d->dtype), "mhsa: bad dtype %d", d->dtype);
+  NR_CHECK_ARG(d->n >= 0 && d->L >= 1 && d->L <= 64 && d->d_model >= 1 && d->heads >= 1 && d->d_head >= 1,
+               "mhsa: bad shape n=%d L=%d d_model=%d heads=%d d_head=%d", d->n, d->L, d->d_model, d->heads, d->d_head);
+  const int ch = nr_chunk(d->dtype);
+  NR_CHECK_ARG((3 * d->heads * d->d_head) % ch == 0, "mhsa: 3*news_dim=%d must be a multiple of %d for this dtype",
+               3 * d->heads * d->d_head, ch);
+  NR_CHECK_ARG(d->ldx >= round_up(d->d_model, ch) && d->ldw >= round_up(d->d_model, ch),
+               "mhsa: ldx=%d / ldw=%d must cover d_model=%d rounded up to %d", d->ldx, d->ldw, d->d_model, ch);
+  NR_CHECK_ARG(d->x && d->w_qkv && d->b_qkv, "mhsa: null operand");
+  NR_CHECK_ARG(d->p_in >= 0.f && d->p_in < 1.f && d->p_out >= 0.f && d->p_out < 1.f, "mhsa: dropout p out of range");
+  NR_CHECK_ARG((uint64_t)d->n * d->L * (uint64_t)(3 * d->heads * d->d_head) < 0xffffffffull, "mhsa: problem too large for 32-bit element counters");
+  return NR_OK;
+}
+
+extern "C" {
+
+int nr_version(void) { return 100; }
+
+int nr_last_error(char* buf, size_t n) {
+  if (buf && n) {
+    strncpy(buf, g_err, n - 1);
+    buf[n - 1] = 0;
+  }
+  return (int)strlen(g_err);
+}
+
+// ---------------------------------------------------------------------------------------- MHSA
+int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
+  int rc = mhsa_check(d);
+  if (rc) return rc;
+  if (d->n == 0) return NR_OK;
+  NR_CHECK_ARG(qkv && y, "mhsa_fwd: null output");
+  hipStream_t s = (hipStream_t)stream;
+  const int N = d->heads * d->d_head, M = d->n * d->L, Kp = round_up(d->d_model, nr_chunk(d->dtype));
+  RowSrc A;
+  if ((rc = mhsa_rows(d, &A))) return rc;
+  EpiArgs ep = store_epi(qkv, 3 * N, d->dtype, d->b_qkv, 0);
+  if ((rc = nr_launch_gemm_nt(d->dtype, A, d->w_qkv, d->ldw, M, 3 * N, Kp, EPI_STORE, ep, s))) return rc;
+  return nr_launch_attn(false, d->dtype, qkv, d->mask, y, nullptr, nullptr, d->n, d->L, d->heads, d->d_head,
+                        nr_make_drop(d->p_out, d->seed_out), s);
+}
+
+int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dqkv, const void* w_qkv_t, int ldwt,
+                float* dw_qkv, float* db_qkv, void* dx, float* dtable, nr_stream_t stream) {
+  int rc = mhsa_check(d);
+  if (rc) return rc;
+  if (d->n == 0) return NR_OK;
+  NR_CHECK_ARG(qkv && dy && dqkv && dw_qkv && db_qkv, "mhsa_bwd: null operand");
+  hipStream_t s = (hipStream_t)stream;
+  const int N = d->heads * d->d_head, M = d->n * d->L, ch = nr_chunk(d->dtype), Kp = round_up(d->d_model, ch);
+  RowSrc A;
+  if ((rc = mhsa_rows(d, &A))) return rc;
+  if ((rc = nr_launch_attn(true, d->dtype, qkv, d->mask, nullptr, dy, dqkv, d->n, d->L, d->heads, d->d_head,
+                           nr_make_drop(d->p_out, d->seed_out), s)))
+    return rc;
+  // dW_qkv[3N, d_model] += dQKV^T . X ; db += colsum(dQKV)
+  if ((rc = nr_launch_gemm_tn(d->dtype, dqkv, 3 * N, A, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model, s))) return rc;
+  if (dx != nullptr || dtable != nullptr) {
+    NR_CHECK_ARG(w_qkv_t != nullptr && ldwt >= 3 * N, "mhsa_bwd: w_qkv_t [d_model, >=3N] needed for dx / dtable");
+    RowSrc G = dense_rows(dqkv, 3 * N, 3 * N);
+    if (d->src_kind == NR_SRC_GATHER) {
+      NR_CHECK_ARG(dtable != nullptr && dx == nullptr, "mhsa_bwd: gather source takes dtable, not dx");
+      NR_CHECK_ARG(d->d_model % 4 == 0, "mhsa_bwd: d_model=%d must be a multiple of 4", d->d_model);
+      EpiArgs ep = store_epi(dtable, d->d_model, NR_F32, nullptr, 0);
+      ep.ids = d->ids; ep.ids_stride = 1; ep.Dtrue = d->d_model; ep.drop = nr_make_drop(d->p_in, d->seed_in);
+      rc = nr_launch_gemm_nt(d->dtype, G, w_qkv_t, ldwt, M, d->d_model, 3 * N, EPI_SCATTER, ep, s);
+    } else {
+      NR_CHECK_ARG(dx != nullptr && dtable == nullptr, "mhsa_bwd: dense source takes dx, not dtable");
+      NR_CHECK_ARG(d->p_in == 0.f, "mhsa_bwd: input dropout on a dense source is not supported");
+      NR_CHECK_ARG(d->d_model % 4 == 0, "mhsa_bwd: d_model=%d must be a multiple of 4", d->d_model);
+      EpiArgs ep = store_epi(dx, d->ldx, d->dtype, nullptr, 0);
+      rc = nr_launch_gemm_nt(d->dtype, G, w_qkv_t, ldwt, M, d->d_model, 3 * N, EPI_STORE, ep, s);
+    }
+  }
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------- Conv1d k=3
+static int conv_rows(const nr_conv_desc* d, RowSrc* out) {
+  NR_CHECK_ARG(d != nullptr, "conv1d: null descriptor");
+  NR_CHECK_ARG(dtype_ok(d->dtype), "conv1d: bad dtype %d", d->dtype);
+  const int ch = nr_chunk(d->dtype);
+  NR_CHECK_ARG(d->n >= 0 && d->T >= 1 && d->D >= 1 && d->N >= 1 && d->Dp >= d->D && d->Dp % ch == 0,
+               "conv1d: bad shape n=%d T=%d D=%d Dp=%d N=%d", d->n, d->T, d->D, d->Dp, d->N);
+  NR_CHECK_ARG(d->N % ch == 0, "conv1d: N=%d must be a multiple of %d", d->N, ch);
+  NR_CHECK_ARG(d->table && d->ids && d->w_pack && d->bias && d->ids_stride >= 1, "conv1d: null operand");
+  NR_CHECK_ARG((uint64_t)d->n * d->T * (uint64_t)d->D < 0xffffffffull, "conv1d: problem too large for 32-bit element counters");
+  RowSrc s = dense_rows(d->table, d->Dp, d->D);
+  s.kind = ROWS_IM2COL3;
+  s.ids = d->ids; s.ids_stride = d->ids_stride; s.Tlen = d->T;
+  s.drop = nr_make_drop(d->p_in, d->seed_in);
+  *out = s;
+  return NR_OK;
+}
+
+int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream) {
+  RowSrc A;
+  int rc = conv_rows(d, &A);
+  if (rc) return rc;
+  if (d->n == 0) return NR_OK;
+  NR_CHECK_ARG(y != nullptr, "conv1d_fwd: null output");
+  EpiArgs ep = store_epi(y, d->N, d->dtype, d->bias, 0);
+  return nr_launch_gemm_nt(d->dtype, A, d->w_pack, 3 * d->Dp, d->n * d->T, d->N, 3 * d->Dp, EPI_STORE, ep, (hipStream_t)stream);
+}
+
+int nr_conv1d_k3_bwd(const nr_conv_desc* d, const void* dy, float* dw_pack, float* db, nr_stream_t stream) {
+  RowSrc A;
+  int rc = conv_rows(d, &A);
+  if (rc) return rc;
+  if (d->n == 0) return NR_OK;
+  NR_CHECK_ARG(dy && dw_pack && db, "conv1d_bwd: null operand");
+  return nr_launch_gemm_tn(d->dtype, dy, d->N, A, dw_pack, 3 * d->Dp, db, d->n * d->T, d->N, 3 * d->Dp, d->N, 3 * d->Dp,
+                           (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------- additive pooling
+static int pool_check(const nr_pool_desc* d) {
+  NR_CHECK_ARG(d != nullptr, "additive_pool: null descriptor");
+  NR_CHECK_ARG(dtype_ok(d->dtype), "additive_pool: bad dtype %d", d->dtype);
+  const int ch = nr_chunk(d->dtype);
+  NR_CHECK_ARG(d->n >= 0 && d->L >= 1 && d->L <= 64 && d->N >= 1 && d->q >= 1, "additive_pool: bad shape n=%d L=%d N=%d q=%d", d->n, d->L,
+               d->N, d->q);
+  NR_CHECK_ARG(d->N % ch == 0 && d->q % ch == 0, "additive_pool: N=%d and q=%d must be multiples of %d for this dtype", d->N, d->q, ch);
+  NR_CHECK_ARG(d->ldw1 >= d->N, "additive_pool: ldw1=%d < N=%d", d->ldw1, d->N);
+  NR_CHECK_ARG(d->x && d->w1 && d->b1 && d->w2 && d->b2, "additive_pool: null operand");
+  return NR_OK;
+}
+
+int nr_additive_pool_fwd(const nr_pool_desc* d, void* e, float* alpha, float* out, int ld_out, nr_stream_t stream) {
+  int rc = pool_check(d);
+  if (rc) return rc;
+  if (d->n == 0) return NR_OK;
+  NR_CHECK_ARG(e && alpha && out && ld_out >= d->N, "additive_pool_fwd: null output / ld_out");
+  hipStream_t s = (hipStream_t)stream;
+  RowSrc A = dense_rows(d->x, d->N, d->N);
+  EpiArgs ep = store_epi(e, d->q, d->dtype, d->b1, 1);
+  if ((rc = nr_launch_gemm_nt(d->dtype, A, d->w1, d->ldw1, d->n * d->L, d->q, d->N, EPI_STORE, ep, s))) return rc;
+  return nr_launch_pool_core_fwd(d->dtype, d->x, e, d->w2, d->b2, d->mask, alpha, out, ld_out, d->n, d->L, d->N, d->q, s);
+}
+
+int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alpha, const float* g, int ld_g, const void* w1_t,
+                         int ldw1t, void* dpre, float* partial, float* dw1, float* db1, float* dw2, float* db2, void* dx,
+                         nr_stream_t stream) {
+  int rc = pool_check(d);
+  if (rc) return rc;
+  if (d->n == 0) return NR_OK;
+  NR_CHECK_ARG(e && alpha && g && dpre && partial && dw1 && db1 && dw2 && db2, "additive_pool_bwd: null operand");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = d->n * d->L;
+  if ((rc = nr_launch_pool_core_bwd(d->dtype, d->x, e, d->w2, alpha, g, ld_g, dpre, partial, dw2, db2, d->n, d->L, d->N, d->q, s)))
+    return rc;
+  RowSrc X = dense_rows(d->x, d->N, d->N);
+  if ((rc = nr_launch_gemm_tn(d->dtype, dpre, d->q, X, dw1, d->N, db1, M, d->q, d->N, d->q, d->N, s))) return rc;
+  if (dx != nullptr) {
+    NR_CHECK_ARG(w1_t != nullptr && ldw1t >= d->q, "additive_pool_bwd: w1_t [N, >=q] needed for dx");
+    RowSrc P = dense_rows(dpre, d->q, d->q);
+    EpiArgs ep = store_epi(dx, d->N, d->dtype, nullptr, 0);
+    ep.rowscale = alpha; ep.G = g; ep.ldg = ld_g; ep.L = d->L;
+    rc = nr_launch_gemm_nt(d->dtype, P, w1_t, ldw1t, M, d->N, d->q, EPI_POOLBWD, ep, s);
+  }
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------- gather + Linear
+static int linear_rows(const nr_linear_desc* d, RowSrc* out) {
+  NR_CHECK_ARG(d != nullptr, "linear: null descriptor");
+  NR_CHECK_ARG(dtype_ok(d->dtype), "linear: bad dtype %d", d->dtype);
+  const int ch = nr_chunk(d->dtype);
+  NR_CHECK_ARG(d->M >= 0 && d->K >= 1 && d->N >= 1, "linear: bad shape M=%d K=%d N=%d", d->M, d->K, d->N);
+  NR_CHECK_ARG(d->ldx >= round_up(d->K, ch) && d->ldw >= round_up(d->K, ch), "linear: ldx=%d / ldw=%d must cover K=%d rounded up to %d",
+               d->ldx, d->ldw, d->K, ch);
+  NR_CHECK_ARG(d->x && d->w, "linear: null operand");
+  RowSrc s = dense_rows(d->x, d->ldx, d->K);
+  if (d->src_kind == NR_SRC_GATHER) {
+    NR_CHECK_ARG(d->ids != nullptr && d->ids_stride >= 1, "linear: gather source without ids");
+    s.kind = ROWS_GATHER; s.ids = d->ids; s.ids_stride = d->ids_stride;
+  } else {
+    NR_CHECK_ARG(d->src_kind == NR_SRC_DENSE, "linear: bad src_kind %d", d->src_kind);
+  }
+  *out = s;
+  return NR_OK;
+}
+
+int nr_linear_fwd(const nr_linear_desc* d, float* out, int ld_out, nr_stream_t stream) {
+  RowSrc A;
+  int rc = linear_rows(d, &A);
+  if (rc) return rc;
+  if (d->M == 0) return NR_OK;
+  NR_CHECK_ARG(out != nullptr && ld_out >= d->N, "linear_fwd: null output / ld_out");
+  EpiArgs ep = store_epi(out, ld_out, NR_F32, d->bias, 0);
+  return nr_launch_gemm_nt(d->dtype, A, d->w, d->ldw, d->M, d->N, round_up(d->K, nr_chunk(d->dtype)), EPI_STORE, ep, (hipStream_t)stream);
+}
+
+int nr_linear_bwd(const nr_linear_desc* d, const float* dout, int ld_dout, void* dout_ws, float* dw, float* db, float* dtable,
+                  nr_stream_t stream) {
+  RowSrc A;
+  int rc = linear_rows(d, &A);
+  if (rc) return rc;
+  if (d->M == 0) return NR_OK;
+  NR_CHECK_ARG(dout && dout_ws && dw && db, "linear_bwd: null operand");
+  hipStream_t s = (hipStream_t)stream;
+  const int ch = nr_chunk(d->dtype), Nc = round_up(d->N, ch), Kp = round_up(d->K, ch);
+  if ((rc = nr_launch_cast_rows(d->dtype, dout, ld_dout, dout_ws, Nc, d->M, d->N, s))) return rc;
+  if ((rc = nr_launch_gemm_tn(d->dtype, dout_ws, Nc, A, dw, d->K, db, d->M, Nc, Kp, d->N, d->K, s))) return rc;
+  if (dtable != nullptr) {
+    NR_CHECK_ARG(d->src_kind == NR_SRC_GATHER, "linear_bwd: dtable needs a gather source");
+    NR_CHECK_ARG(d->w_t != nullptr && d->ldwt >= Nc, "linear_bwd: w_t [K, >=N rounded up] needed for dtable");
+    RowSrc G = dense_rows(dout_ws, Nc, Nc);
+    EpiArgs ep = store_epi(dtable, d->K, NR_F32, nullptr, 0);
+    ep.ids = d->ids; ep.ids_stride = d->ids_stride; ep.Dtrue = d->K;
+    rc = nr_launch_gemm_nt(d->dtype, G, d->w_t, d->ldwt, d->M, d->K, Nc, EPI_SCATTER, ep, s);
+  }
+  return rc;
+}
+
+}  // extern "C"

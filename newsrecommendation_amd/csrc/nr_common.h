@@ -1,0 +1,87 @@
+// Shared device/host helpers for libnrhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/nrhip.h"
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define NR_WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------------------
+void nr_set_error(const char* fmt, ...);
+#define NR_CHECK_ARG(cond, ...)                    \
+  do {                                             \
+    if (!(cond)) {                                 \
+      nr_set_error(__VA_ARGS__);                   \
+      return NR_ERR_ARG;                           \
+    }                                              \
+  } while (0)
+#define NR_CHECK_HIP(expr)                                                        \
+  do {                                                                            \
+    hipError_t e__ = (expr);                                                      \
+    if (e__ != hipSuccess) {                                                      \
+      nr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return NR_ERR_HIP;                                                          \
+    }                                                                             \
+  } while (0)
+#define NR_CHECK_LAUNCH() NR_CHECK_HIP(hipGetLastError())
+
+static inline int nr_elt_size(int dtype) { return dtype == NR_BF16 ? 2 : 4; }
+// K granule of one 16-byte chunk in elements
+static inline int nr_chunk(int dtype) { return dtype == NR_BF16 ? 8 : 4; }
+
+// ---- counter-based dropout RNG ---------------------------------------------------------
+// keep(seed, idx) is a pure function of (seed, element counter): forward and backward
+// regenerate the same Bernoulli draw without storing a mask.
+__host__ __device__ __forceinline__ uint32_t nr_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t nr_drop_key(uint32_t seed) { return nr_mix32(seed * 0x9e3779b9u + 0x7f4a7c15u); }
+__host__ __device__ __forceinline__ uint32_t nr_drop_thresh(float p) {
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+}
+// returns 1 if element idx is kept
+__host__ __device__ __forceinline__ bool nr_keep(uint32_t key, uint32_t idx, uint32_t thresh) {
+  return nr_mix32(idx ^ key) >= thresh;
+}
+
+struct DropCfg {
+  uint32_t key;     // nr_drop_key(seed)
+  uint32_t thresh;  // drop if hash < thresh ; 0 = dropout off
+  float scale;      // 1/(1-p)
+};
+static inline DropCfg nr_make_drop(float p, uint32_t seed) {
+  DropCfg d;
+  d.key = nr_drop_key(seed);
+  d.thresh = p > 0.f ? nr_drop_thresh(p) : 0u;
+  d.scale = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+  return d;
+}
+
+// ---- small device helpers ----------------------------------------------------------------
+template <typename T> struct EltTraits;
+template <> struct EltTraits<float> { static constexpr int CH = 4; static constexpr int DT = NR_F32; };
+template <> struct EltTraits<bf16_t> { static constexpr int CH = 8; static constexpr int DT = NR_BF16; };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+template <typename T> __device__ __forceinline__ float to_f(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v) { return (T)v; }

@@ -1,0 +1,48 @@
+// Internal GEMM interface of libnrhip: MFMA tiles (16x16x32 bf16 / 16x16x4 f32) on gfx950.
+//   NT :  C[M,N]  = epi( rows(A)[M,K] . B[N,K]^T )           activations x packed weights
+//   TN :  dW[N,K] += dC[M,N]^T . rows(A)[M,K]  (+ db = colsum dC)   weight gradients, split over M
+// rows(A) is a "row source": dense rows, rows gathered from a table by id (embedding
+// lookup fused into the operand load), or the im2col view of a k=3 convolution over a
+// gathered [T, D] block; optional counter-based dropout is applied while staging.
+#pragma once
+#include "nr_common.h"
+
+enum { ROWS_DENSE = 0, ROWS_GATHER = 1, ROWS_IM2COL3 = 2 };
+
+struct RowSrc {
+  const void* base;    // dense: [M, ld]; gather: table [V, ld]; im2col3: table [V, Tlen*ld]
+  const int32_t* ids;  // gather: id of row m = ids[m*ids_stride]; im2col3: id of block s = ids[s*ids_stride]
+  int ld;              // elements between consecutive rows (im2col3: between tokens, = Dp)
+  int ids_stride;
+  int kind;
+  int Tlen;            // im2col3: tokens per block
+  int Dtrue;           // dropout: elements per logical row (index = row*Dtrue + col, applied for col < Dtrue)
+  DropCfg drop;
+};
+
+enum {
+  EPI_STORE = 0,    // C = acc (+ bias[n]) (tanh)
+  EPI_POOLBWD = 1,  // C = acc + rowscale[m] * G[(m / L) * ldg + n]
+  EPI_SCATTER = 2,  // dtable[ids[m]*ldc + n] += keep(m*Dtrue+n) ? acc*scale : 0   (ids[m] != 0, n < Dtrue)
+};
+
+struct EpiArgs {
+  void* C;
+  int ldc;
+  int out_dtype;          // NR_F32 / NR_BF16 for EPI_STORE / EPI_POOLBWD
+  const float* bias;      // [N] or null
+  int act_tanh;
+  const float* rowscale;  // POOLBWD: alpha [M]
+  const float* G;         // POOLBWD: [n, ldg] fp32
+  int ldg, L;
+  const int32_t* ids;     // SCATTER
+  int ids_stride;
+  int Dtrue;
+  DropCfg drop;           // SCATTER: the forward's input dropout
+};
+
+// C-level launchers (enqueue only).  dtype selects T.
+int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi,
+                      const EpiArgs& ep, hipStream_t stream);
+int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db,
+                      int M, int N, int K, int Nstore, int Kstore, hipStream_t stream);

@@ -1,0 +1,500 @@
+// MFMA GEMMs of libnrhip (gfx950).  See nr_gemm.h for the operator definitions.
+//
+// Tile: 128 x 128 x 32 per workgroup of 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 MFMA
+// tiles of 16 x 16.  Both operands are staged into LDS k-contiguous, so one lane's
+// fragment for a 32-deep k-step is 8 contiguous elements [row][8*(lane>>4) .. +8):
+//   bf16: one v_mfma_f32_16x16x32_bf16 per (m,n) tile per k-step
+//   f32 : eight v_mfma_f32_16x16x4_f32 (sub-step e takes k = 8*(lane>>4)+e from both operands)
+// Global -> register -> LDS double buffering, one barrier per k-step.  The epilogue goes
+// through an fp32 LDS tile so that global stores / atomics are 16-byte, row-contiguous.
+#include "nr_gemm.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, NTHR = 256;
+constexpr int SC = BN + 4;  // fp32 epilogue tile row stride
+
+template <typename T> struct TileCfg {
+  static constexpr int CH = 16 / (int)sizeof(T);  // elements per 16-byte chunk (bf16 8, f32 4)
+  static constexpr int SK = BK + CH;              // LDS row stride in elements (80 B / 144 B)
+  static constexpr int CPR = BK / CH;             // chunks per tile row
+  static constexpr int NCH = BM * CPR / NTHR;     // chunks per thread per operand (2 / 4)
+  static constexpr int RPC = BM / CH;             // rows per permutation class (TN staging)
+  static constexpr size_t STAGE_BYTES = (size_t)2 * 2 * BM * SK * sizeof(T);
+};
+constexpr size_t EPI_BYTES = (size_t)BM * SC * sizeof(float);
+constexpr size_t RED_BYTES = (size_t)16 * 128 * sizeof(float);
+
+template <typename T> constexpr size_t smem_bytes() {
+  return (TileCfg<T>::STAGE_BYTES > EPI_BYTES ? TileCfg<T>::STAGE_BYTES : EPI_BYTES) + RED_BYTES;
+}
+
+union Chunk {
+  uint4 u;
+  float f[4];
+  bf16_t h[8];
+  uint32_t w[4];
+};
+
+// ---- operand row sources ---------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void drop_chunk(Chunk& c, const DropCfg& dr, uint32_t eidx, int col, int Dtrue);
+template <> __device__ __forceinline__ void drop_chunk<float>(Chunk& c, const DropCfg& dr, uint32_t eidx, int col, int Dtrue) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (col + e < Dtrue) c.f[e] = nr_keep(dr.key, eidx + e, dr.thresh) ? c.f[e] * dr.scale : 0.f;
+}
+template <> __device__ __forceinline__ void drop_chunk<bf16_t>(Chunk& c, const DropCfg& dr, uint32_t eidx, int col, int Dtrue) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (col + e < Dtrue) c.h[e] = nr_keep(dr.key, eidx + e, dr.thresh) ? (bf16_t)((float)c.h[e] * dr.scale) : (bf16_t)0.f;
+}
+
+// 16-byte chunk [m][k .. k+CH) of the logical [M, K] operand; zeros outside.
+template <typename T, int KIND>
+__device__ __forceinline__ uint4 load_rows_chunk(const RowSrc& s, int m, int k, int M, int K) {
+  Chunk c;
+  c.u = make_uint4(0, 0, 0, 0);
+  if (m >= M || k >= K) return c.u;
+  const T* p;
+  uint32_t eidx;
+  int col = k;
+  if (KIND == ROWS_DENSE) {
+    p = (const T*)s.base + (size_t)m * s.ld + k;
+    eidx = (uint32_t)m * (uint32_t)s.Dtrue + (uint32_t)k;
+  } else if (KIND == ROWS_GATHER) {
+    const int id = s.ids[(size_t)m * s.ids_stride];
+    p = (const T*)s.base + (size_t)id * s.ld + k;
+    eidx = (uint32_t)m * (uint32_t)s.Dtrue + (uint32_t)k;
+  } else {  // ROWS_IM2COL3: k = tap*Dp + d ; source token t-1+tap of the block
+    const int blk = m / s.Tlen, t = m - blk * s.Tlen;
+    const int tap = k / s.ld, d = k - tap * s.ld;
+    const int tt = t - 1 + tap;
+    if (tt < 0 || tt >= s.Tlen) return c.u;
+    const int id = s.ids[(size_t)blk * s.ids_stride];
+    p = (const T*)s.base + ((size_t)id * s.Tlen + tt) * s.ld + d;
+    eidx = (uint32_t)(blk * s.Tlen + tt) * (uint32_t)s.Dtrue + (uint32_t)d;
+    col = d;
+  }
+  c.u = *reinterpret_cast<const uint4*>(p);
+  if (s.drop.thresh) drop_chunk<T>(c, s.drop, eidx, col, s.Dtrue);
+  return c.u;
+}
+
+// ---- MFMA fragments --------------------------------------------------------------------
+struct F8 { float v[8]; };
+template <typename T> struct FragOf;
+template <> struct FragOf<bf16_t> { using type = bf16x8; };
+template <> struct FragOf<float> { using type = F8; };
+
+__device__ __forceinline__ void read_frag(bf16x8& f, const bf16_t* p) { f = *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void read_frag(F8& f, const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+__device__ __forceinline__ void mma(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(f32x4& acc, const F8& a, const F8& b) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[e], b.v[e], acc, 0, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ void mma_tile_step(f32x4 (&acc)[4][4], const T* sA, const T* sB, int wm, int wn, int lane) {
+  using TL = TileCfg<T>;
+  typename FragOf<T>::type a[4], b[4];
+  const int fr = lane & 15, fk = (lane >> 4) * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) read_frag(a[i], sA + (wm * 64 + i * 16 + fr) * TL::SK + fk);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) read_frag(b[j], sB + (wn * 64 + j * 16 + fr) * TL::SK + fk);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mma(acc[i][j], a[i], b[j]);
+}
+
+// ---- epilogue emit: 4 consecutive columns of one row ------------------------------------
+template <int EPI>
+__device__ __forceinline__ void emit4(const EpiArgs& ep, int m, int n, int N, f32x4 v) {
+  if (EPI == EPI_POOLBWD) {
+    const float rs = ep.rowscale[m];
+    const float* g = ep.G + (size_t)(m / ep.L) * ep.ldg + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n + e < N) v[e] += rs * g[e];
+  }
+  if (EPI == EPI_SCATTER) {
+    const int id = ep.ids[(size_t)m * ep.ids_stride];
+    if (id == 0) return;  // padding_idx row receives no gradient
+    float* dst = (float*)ep.C + (size_t)id * ep.ldc + n;
+    const uint32_t eidx = (uint32_t)m * (uint32_t)ep.Dtrue + (uint32_t)n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (n + e >= ep.Dtrue) break;
+      float x = v[e];
+      if (ep.drop.thresh) x = nr_keep(ep.drop.key, eidx + e, ep.drop.thresh) ? x * ep.drop.scale : 0.f;
+      if (x != 0.f) atomicAdd(dst + e, x);
+    }
+    return;
+  }
+  if (ep.out_dtype == NR_F32) {
+    float* dst = (float*)ep.C + (size_t)m * ep.ldc + n;
+    if (n + 4 <= N) {
+      *reinterpret_cast<f32x4*>(dst) = v;
+    } else {
+      for (int e = 0; e < 4 && n + e < N; ++e) dst[e] = v[e];
+    }
+  } else {
+    bf16_t* dst = (bf16_t*)ep.C + (size_t)m * ep.ldc + n;
+    if (n + 4 <= N) {
+      bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(dst) = o;
+    } else {
+      for (int e = 0; e < 4 && n + e < N; ++e) dst[e] = (bf16_t)v[e];
+    }
+  }
+}
+
+// =========================================================================================
+// NT
+// =========================================================================================
+template <typename T, int KIND, int EPI>
+__global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __restrict__ B, int ldb, int M, int N, int K,
+                                                       EpiArgs ep, int tilesM, int tilesN) {
+  using TL = TileCfg<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sA = reinterpret_cast<T*>(smem);        // [2][BM*SK]
+  T* sB = sA + 2 * BM * TL::SK;              // [2][BN*SK]
+  float* sC = reinterpret_cast<float*>(smem);
+
+  // XCD-aware mapping: blocks b, b+8, ... share an XCD (and its L2); give one XCD all the
+  // N-tiles of an M-tile back to back so the gathered A rows are re-read from that L2.
+  const int b = blockIdx.x, xcd = b & 7, local = b >> 3;
+  const int tm = (local / tilesN) * 8 + xcd, tn = local % tilesN;
+  if (tm >= tilesM) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+
+  uint4 ra[TL::NCH], rb[TL::NCH];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < TL::NCH; ++i) {
+      const int c = tid + i * NTHR, row = c / TL::CPR, kc = (c % TL::CPR) * TL::CH;
+      ra[i] = load_rows_chunk<T, KIND>(A, m0 + row, k0 + kc, M, K);
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (n0 + row < N && k0 + kc < K) z = *reinterpret_cast<const uint4*>(B + (size_t)(n0 + row) * ldb + k0 + kc);
+      rb[i] = z;
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < TL::NCH; ++i) {
+      const int c = tid + i * NTHR, row = c / TL::CPR, kc = (c % TL::CPR) * TL::CH;
+      *reinterpret_cast<uint4*>(sA + buf * BM * TL::SK + row * TL::SK + kc) = ra[i];
+      *reinterpret_cast<uint4*>(sB + buf * BN * TL::SK + row * TL::SK + kc) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    mma_tile_step<T>(acc, sA + cur * BM * TL::SK, sB + cur * BN * TL::SK, wm, wn, lane);
+    if (kt + 1 < nk) swrite(cur ^ 1);
+    __syncthreads();
+  }
+
+  // accumulators -> fp32 LDS tile (bias / tanh applied here, column is lane-constant)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = wn * 64 + j * 16 + (lane & 15);
+    float bv = 0.f;
+    if (EPI == EPI_STORE && ep.bias != nullptr && n0 + col < N) bv = ep.bias[n0 + col];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        float v = acc[i][j][r] + bv;
+        if (EPI == EPI_STORE && ep.act_tanh) v = tanhf(v);
+        sC[row * SC + col] = v;
+      }
+  }
+  __syncthreads();
+  for (int u = tid; u < BM * (BN / 4); u += NTHR) {
+    const int row = u / (BN / 4), c0 = (u % (BN / 4)) * 4;
+    const int m = m0 + row, n = n0 + c0;
+    if (m < M && n < N) emit4<EPI>(ep, m, n, N, *reinterpret_cast<const f32x4*>(sC + row * SC + c0));
+  }
+}
+
+// =========================================================================================
+// TN : dW[N,K] += sum_m dC[m,N]^T rows(A)[m,K]   (contraction over rows, split across blocks)
+// Both operands arrive contraction-major in memory, so they are transposed while staging.
+// A thread's 16-byte chunk holds CH consecutive tile rows; element e of chunk nc is written
+// to LDS row rho = e*(128/CH) + nc so that simultaneous writes land on consecutive LDS rows
+// (<= 2-way bank conflict for bf16).  The MFMA tile is therefore computed in permuted row /
+// column order and un-permuted when the accumulators are written to the epilogue tile.
+// =========================================================================================
+template <typename T> __device__ __forceinline__ int unperm(int r) {
+  using TL = TileCfg<T>;
+  return (r % TL::RPC) * TL::CH + r / TL::RPC;
+}
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(NTHR) void gemm_tn_kernel(const T* __restrict__ dC, int ldc, RowSrc A, float* __restrict__ dW,
+                                                       int ldw, float* __restrict__ db, int M, int N, int K, int Nstore, int Kstore,
+                                                       int tilesK, int rows_per_split) {
+  using TL = TileCfg<T>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sA = reinterpret_cast<T*>(smem);
+  T* sB = sA + 2 * BM * TL::SK;
+  float* sC = reinterpret_cast<float*>(smem);
+  float* sRed = reinterpret_cast<float*>(smem + (TL::STAGE_BYTES > EPI_BYTES ? TL::STAGE_BYTES : EPI_BYTES));
+
+  const int tn = blockIdx.x / tilesK, tk = blockIdx.x % tilesK;
+  const int n0 = tn * BM, k0 = tk * BN;
+  const int mbeg = blockIdx.y * rows_per_split;
+  const int mend = min(M, mbeg + rows_per_split);
+  if (mbeg >= mend) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  const bool do_db = (db != nullptr) && (tk == 0);
+
+  constexpr bool IS_BF16 = (sizeof(T) == 2);
+  // staging units: bf16: (nc = tid&15, row pair mp = tid>>4); f32: 4 units (nc = tid&31, m = (tid>>5) + 8*i)
+  constexpr int NU = IS_BF16 ? 2 : 4;
+  uint4 ra[NU], rb[NU];
+  float colsum[TL::CH];
+#pragma unroll
+  for (int e = 0; e < TL::CH; ++e) colsum[e] = 0.f;
+
+  auto gload = [&](int mt) {
+    if (IS_BF16) {
+      const int nc = tid & 15, mp = tid >> 4;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int m = mt + 2 * mp + h;
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (m < mend && n0 + nc * 8 < N) z = *reinterpret_cast<const uint4*>(dC + (size_t)m * ldc + n0 + nc * 8);
+        ra[h] = z;
+        rb[h] = load_rows_chunk<T, KIND>(A, m, k0 + nc * 8, mend, K);
+      }
+    } else {
+      const int nc = tid & 31;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mt + (tid >> 5) + 8 * i;
+        uint4 z = make_uint4(0, 0, 0, 0);
+        if (m < mend && n0 + nc * 4 < N) z = *reinterpret_cast<const uint4*>(dC + (size_t)m * ldc + n0 + nc * 4);
+        ra[i] = z;
+        rb[i] = load_rows_chunk<T, KIND>(A, m, k0 + nc * 4, mend, K);
+      }
+    }
+  };
+  auto swrite = [&](int buf) {
+    T* a = sA + buf * BM * TL::SK;
+    T* bq = sB + buf * BN * TL::SK;
+    if (IS_BF16) {
+      const int nc = tid & 15, mp = tid >> 4;
+      Chunk a0, a1, b0, b1;
+      a0.u = ra[0]; a1.u = ra[1]; b0.u = rb[0]; b1.u = rb[1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int rho = e * 16 + nc;
+        bf16x2 pa = {a0.h[e], a1.h[e]};
+        bf16x2 pb = {b0.h[e], b1.h[e]};
+        *reinterpret_cast<bf16x2*>(reinterpret_cast<bf16_t*>(a) + rho * TL::SK + 2 * mp) = pa;
+        *reinterpret_cast<bf16x2*>(reinterpret_cast<bf16_t*>(bq) + rho * TL::SK + 2 * mp) = pb;
+        if (do_db) colsum[e] += (float)a0.h[e] + (float)a1.h[e];
+      }
+    } else {
+      const int nc = tid & 31;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ml = (tid >> 5) + 8 * i;
+        Chunk ca, cb;
+        ca.u = ra[i]; cb.u = rb[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int rho = e * 32 + nc;
+          reinterpret_cast<float*>(a)[rho * TL::SK + ml] = ca.f[e];
+          reinterpret_cast<float*>(bq)[rho * TL::SK + ml] = cb.f[e];
+          if (do_db) colsum[e] += ca.f[e];
+        }
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (mend - mbeg + BK - 1) / BK;
+  gload(mbeg);
+  swrite(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(mbeg + (kt + 1) * BK);
+    mma_tile_step<T>(acc, sA + cur * BM * TL::SK, sB + cur * BN * TL::SK, wm, wn, lane);
+    if (kt + 1 < nk) swrite(cur ^ 1);
+    __syncthreads();
+  }
+
+  // bias gradient: column sums of dC over this block's rows
+  if (do_db) {
+    if (IS_BF16) {
+      const int nc = tid & 15, mp = tid >> 4;
+#pragma unroll
+      for (int e = 0; e < TL::CH; ++e) sRed[mp * 128 + nc * 8 + e] = colsum[e];
+    } else {
+      const int nc = tid & 31, g = tid >> 5;
+#pragma unroll
+      for (int e = 0; e < TL::CH; ++e) sRed[g * 128 + nc * 4 + e] = colsum[e];
+    }
+  }
+  // accumulators -> epilogue tile in natural (n, k) order
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int kl = unperm<T>(wn * 64 + j * 16 + (lane & 15));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nl = unperm<T>(wm * 64 + i * 16 + (lane >> 4) * 4 + r);
+        sC[nl * SC + kl] = acc[i][j][r];
+      }
+  }
+  __syncthreads();
+  if (do_db && tid < 128 && n0 + tid < Nstore) {
+    float s = 0.f;
+    constexpr int G = IS_BF16 ? 16 : 8;
+#pragma unroll
+    for (int g = 0; g < G; ++g) s += sRed[g * 128 + tid];
+    atomicAdd(db + n0 + tid, s);
+  }
+  for (int u = tid; u < BM * (BN / 4); u += NTHR) {
+    const int row = u / (BN / 4), c0 = (u % (BN / 4)) * 4;
+    const int n = n0 + row, k = k0 + c0;
+    if (n < Nstore && k < Kstore) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * SC + c0);
+      float* dst = dW + (size_t)n * ldw + k;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k + e < Kstore) atomicAdd(dst + e, v[e]);
+    }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------
+template <typename K> int set_smem(K kernel, size_t bytes) {
+  NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return NR_OK;
+}
+
+template <typename T, int KIND, int EPI>
+int launch_nt_t(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
+  const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
+  const int grid = ((tilesM + 7) / 8) * 8 * tilesN;
+  auto kern = gemm_nt_kernel<T, KIND, EPI>;
+  const size_t smem = smem_bytes<T>();
+  int rc = set_smem(kern, smem);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), smem, stream, A, (const T*)B, ldb, M, N, K, ep, tilesM, tilesN);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+template <typename T, int KIND>
+int launch_nt_k(const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi, const EpiArgs& ep, hipStream_t s) {
+  switch (epi) {
+    case EPI_STORE: return launch_nt_t<T, KIND, EPI_STORE>(A, B, ldb, M, N, K, ep, s);
+    case EPI_POOLBWD: return launch_nt_t<T, KIND, EPI_POOLBWD>(A, B, ldb, M, N, K, ep, s);
+    case EPI_SCATTER: return launch_nt_t<T, KIND, EPI_SCATTER>(A, B, ldb, M, N, K, ep, s);
+  }
+  nr_set_error("gemm_nt: bad epilogue %d", epi);
+  return NR_ERR_ARG;
+}
+
+template <typename T>
+int launch_nt_d(const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi, const EpiArgs& ep, hipStream_t s) {
+  switch (A.kind) {
+    case ROWS_DENSE: return launch_nt_k<T, ROWS_DENSE>(A, B, ldb, M, N, K, epi, ep, s);
+    case ROWS_GATHER: return launch_nt_k<T, ROWS_GATHER>(A, B, ldb, M, N, K, epi, ep, s);
+    case ROWS_IM2COL3:
+      if (epi == EPI_STORE) return launch_nt_t<T, ROWS_IM2COL3, EPI_STORE>(A, B, ldb, M, N, K, ep, s);
+      break;
+  }
+  nr_set_error("gemm_nt: unsupported row source %d / epilogue %d", A.kind, epi);
+  return NR_ERR_ARG;
+}
+
+template <typename T, int KIND>
+int launch_tn_t(const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
+                int Kstore, hipStream_t stream) {
+  const int tilesN = (N + BM - 1) / BM, tilesK = (K + BN - 1) / BN;
+  // split the contraction so that the grid has ~8 blocks per CU worth of work at most
+  int splits = (256 * 4 + tilesN * tilesK - 1) / (tilesN * tilesK);
+  int rps = (M + splits - 1) / splits;
+  rps = ((rps + BK - 1) / BK) * BK;
+  if (rps < 8 * BK) rps = 8 * BK;
+  splits = (M + rps - 1) / rps;
+  auto kern = gemm_tn_kernel<T, KIND>;
+  const size_t smem = smem_bytes<T>();
+  int rc = set_smem(kern, smem);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3(tilesN * tilesK, splits), dim3(NTHR), smem, stream, (const T*)dC, ldc, A, dW, ldw, db, M, N,
+                     K, Nstore, Kstore, tilesK, rps);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+template <typename T>
+int launch_tn_d(const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
+                int Kstore, hipStream_t s) {
+  switch (A.kind) {
+    case ROWS_DENSE: return launch_tn_t<T, ROWS_DENSE>(dC, ldc, A, dW, ldw, db, M, N, K, Nstore, Kstore, s);
+    case ROWS_GATHER: return launch_tn_t<T, ROWS_GATHER>(dC, ldc, A, dW, ldw, db, M, N, K, Nstore, Kstore, s);
+    case ROWS_IM2COL3: return launch_tn_t<T, ROWS_IM2COL3>(dC, ldc, A, dW, ldw, db, M, N, K, Nstore, Kstore, s);
+  }
+  nr_set_error("gemm_tn: bad row source %d", A.kind);
+  return NR_ERR_ARG;
+}
+
+}  // namespace
+
+int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi, const EpiArgs& ep,
+                      hipStream_t stream) {
+  const int ch = nr_chunk(dtype);
+  NR_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+  NR_CHECK_ARG(K % ch == 0 && ldb % ch == 0 && A.ld % ch == 0, "gemm_nt: K=%d ldb=%d lda=%d must be multiples of %d", K, ldb, A.ld, ch);
+  NR_CHECK_ARG(((uintptr_t)A.base & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_nt: operands must be 16-byte aligned");
+  if (epi != EPI_SCATTER) NR_CHECK_ARG(ep.ldc % 4 == 0 && ((uintptr_t)ep.C & 15) == 0, "gemm_nt: output ld %d / alignment", ep.ldc);
+  return dtype == NR_BF16 ? launch_nt_d<bf16_t>(A, B, ldb, M, N, K, epi, ep, stream)
+                          : launch_nt_d<float>(A, B, ldb, M, N, K, epi, ep, stream);
+}
+
+int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db, int M, int N,
+                      int K, int Nstore, int Kstore, hipStream_t stream) {
+  const int ch = nr_chunk(dtype);
+  NR_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
+  NR_CHECK_ARG(N % ch == 0 && K % ch == 0 && ldc % ch == 0 && A.ld % ch == 0, "gemm_tn: N=%d K=%d ldc=%d lda=%d must be multiples of %d",
+               N, K, ldc, A.ld, ch);
+  NR_CHECK_ARG(((uintptr_t)A.base & 15) == 0 && ((uintptr_t)dC & 15) == 0, "gemm_tn: operands must be 16-byte aligned");
+  return dtype == NR_BF16 ? launch_tn_d<bf16_t>(dC, ldc, A, dW, ldw, db, M, N, K, Nstore, Kstore, stream)
+                          : launch_tn_d<float>(dC, ldc, A, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+}

@@ -1,0 +1,529 @@
+// HBM-bound kernels of libnrhip: additive-attention pooling core (K5), pad-doc blend (K6),
+// scorer + cross-entropy (K8), embedding row gather / scatter-add (K1), parameter packing.
+#include "nr_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// K5 forward core.  e = tanh(fc1(x)) comes from the GEMM epilogue; here:
+//   s_l = <e_l, w2> + b2 ; a_l = exp(s_l) mask_l / (sum + 1e-8) ; out = sum_l a_l x_l
+// (src/model/model_utils.py:23-30), stable form with the row max factored out.
+// One workgroup per sequence; a wave per token for the dot products, a thread per column for
+// the weighted sum (coalesced over the [L, N] tile).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, const T* __restrict__ e,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       const float* __restrict__ mask, float* __restrict__ alpha,
+                                                       float* __restrict__ out, int ld_out, int L, int N, int q) {
+  __shared__ float sS[64];
+  const int seq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const size_t row0 = (size_t)seq * L;
+  for (int l = wid; l < L; l += 4) {
+    const T* er = e + (row0 + l) * q;
+    float p = 0.f;
+    for (int c = lane; c < q; c += 64) p = fmaf((float)er[c], w2[c], p);
+    p = wave_sum(p);
+    if (lane == 0) sS[l] = p + b2[0];
+  }
+  __syncthreads();
+  if (wid == 0) {
+    const float s = lane < L ? sS[lane] : -INFINITY;
+    const float m = wave_max(s);
+    float ex = 0.f;
+    if (lane < L) ex = __expf(s - m) * (mask ? mask[row0 + lane] : 1.f);
+    const float sum = wave_sum(ex);
+    const float a = ex / (sum + 1e-8f * __expf(-m));
+    if (lane < L) {
+      sS[lane] = a;
+      alpha[row0 + lane] = a;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < N; c += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc = fmaf(sS[l], (float)x[(row0 + l) * N + c], acc);
+    out[(size_t)seq * ld_out + c] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5 backward core.  With a = e^/Z, Z = sum e^ + 1e-8:
+//   dA_l = <g, x_l> ; ds_l = a_l (dA_l - sum_u a_u dA_u) ; dpre_l = ds_l w2 (1 - e_l^2)
+//   dw2 += sum_l ds_l e_l ; db2 += sum_l ds_l
+// The direct term a_l g of dx and dpre.W1 are produced together by the GEMM epilogue
+// (EPI_POOLBWD).  Each workgroup handles SEQ_PER_BLOCK sequences and writes one partial row
+// of (dw2 | db2); nr_colsum_kernel reduces the partial rows deterministically.
+// ------------------------------------------------------------------------------------------
+constexpr int POOL_SPB = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ e,
+                                                       const float* __restrict__ w2, const float* __restrict__ alpha,
+                                                       const float* __restrict__ g, int ld_g, T* __restrict__ dpre,
+                                                       float* __restrict__ partial, int n, int L, int N, int q) {
+  __shared__ float sDA[64];
+  __shared__ float sDS[64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float accw[4] = {0.f, 0.f, 0.f, 0.f};  // dw2 columns tid, tid+256, ...
+  float accb = 0.f;
+  for (int s = 0; s < POOL_SPB; ++s) {
+    const int seq = blockIdx.x * POOL_SPB + s;
+    if (seq >= n) break;
+    const size_t row0 = (size_t)seq * L;
+    const float* gr = g + (size_t)seq * ld_g;
+    for (int l = wid; l < L; l += 4) {
+      const T* xr = x + (row0 + l) * N;
+      float p = 0.f;
+      for (int c = lane; c < N; c += 64) p = fmaf(gr[c], (float)xr[c], p);
+      p = wave_sum(p);
+      if (lane == 0) sDA[l] = p;
+    }
+    __syncthreads();
+    if (wid == 0) {
+      const float a = lane < L ? alpha[row0 + lane] : 0.f;
+      const float dA = lane < L ? sDA[lane] : 0.f;
+      const float rd = wave_sum(a * dA);
+      if (lane < L) sDS[lane] = a * (dA - rd);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < L * q; idx += 256) {
+      const int l = idx / q, c = idx - l * q;
+      const float ev = (float)e[(row0 + l) * q + c];
+      dpre[(row0 + l) * q + c] = (T)(sDS[l] * w2[c] * (1.f - ev * ev));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = tid + k * 256;
+      if (c < q) {
+        float t = 0.f;
+        for (int l = 0; l < L; ++l) t = fmaf(sDS[l], (float)e[(row0 + l) * q + c], t);
+        accw[k] += t;
+      }
+    }
+    if (tid == 0) {
+      float t = 0.f;
+      for (int l = 0; l < L; ++l) t += sDS[l];
+      accb += t;
+    }
+    __syncthreads();
+  }
+  float* pr = partial + (size_t)blockIdx.x * (q + 1);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = tid + k * 256;
+    if (c < q) pr[c] = accw[k];
+  }
+  if (tid == 0) pr[q] = accb;
+}
+
+// out[c] += sum_r in[r*ld + c]; one workgroup per 64 columns, fixed summation order.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int rows, int cols, int ld,
+                                                     float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  float s = 0.f;
+  if (c < cols)
+    for (int r = ry; r < rows; r += 4) s += in[(size_t)r * ld + c];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < cols) out[c] += red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+}
+
+// ------------------------------------------------------------------------------------------
+// K6 pad-doc blend
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void blend_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                 const float* __restrict__ pad, T* __restrict__ out, size_t rows, int N) {
+  const size_t total = rows * (size_t)N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / N;
+    const int c = (int)(i - r * N);
+    float v = x[i];
+    if (mask) {
+      const float m = mask[r];
+      v = v * m + pad[c] * (1.f - m);
+    }
+    out[i] = (T)v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void blend_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ mask,
+                                                        float* __restrict__ dx, float* __restrict__ dpad, int rows,
+                                                        int N, int rows_per_block) {
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int c = threadIdx.x; c < N; c += 256) {
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const float d = (float)dout[(size_t)r * N + c];
+      const float m = mask ? mask[r] : 1.f;
+      dx[(size_t)r * N + c] = d * m;
+      acc = fmaf(1.f - m, d, acc);
+    }
+    if (mask && dpad) atomicAdd(dpad + c, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K8 scorer + cross entropy.  One wave per impression.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void score_ce_fwd_kernel(const float* __restrict__ cand, int ld_cand,
+                                                          const float* __restrict__ user,
+                                                          const int64_t* __restrict__ label, float* __restrict__ score,
+                                                          float* __restrict__ lossvec, int C, int N) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* u = user + (size_t)b * N;
+  float my = -INFINITY;  // lane j keeps score j (C <= 64)
+  for (int j = 0; j < C; ++j) {
+    const float* cr = cand + ((size_t)b * C + j) * ld_cand;
+    float p = 0.f;
+    for (int c = lane; c < N; c += 64) p = fmaf(cr[c], u[c], p);
+    p = wave_sum(p);
+    if (lane == j) my = p;
+  }
+  if (lane < C) score[(size_t)b * C + lane] = my;
+  const float m = wave_max(my);
+  const float ex = lane < C ? expf(my - m) : 0.f;
+  const float lse = m + logf(wave_sum(ex));
+  const int lab = (int)label[b];
+  const float sl = __shfl(my, lab, 64);
+  if (lane == 0) lossvec[b] = lse - sl;
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] / (float)n;
+}
+
+__global__ __launch_bounds__(256) void score_ce_bwd_kernel(const float* __restrict__ cand, int ld_cand,
+                                                           const float* __restrict__ user,
+                                                           const int64_t* __restrict__ label,
+                                                           const float* __restrict__ score,
+                                                           const float* __restrict__ gloss,
+                                                           const float* __restrict__ gscore, float inv_b,
+                                                           float* __restrict__ dcand, int ld_dcand,
+                                                           float* __restrict__ duser, int C, int N) {
+  __shared__ float sD[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) {
+    const float s = tid < C ? score[(size_t)b * C + tid] : -INFINITY;
+    const float m = wave_max(s);
+    const float ex = tid < C ? expf(s - m) : 0.f;
+    const float sum = wave_sum(ex);
+    if (tid < C) {
+      float d = (ex / sum - (tid == (int)label[b] ? 1.f : 0.f)) * (gloss ? gloss[0] * inv_b : 0.f);
+      if (gscore) d += gscore[(size_t)b * C + tid];
+      sD[tid] = d;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < N; c += 256) {
+    const float u = user[(size_t)b * N + c];
+    float du = 0.f;
+    for (int j = 0; j < C; ++j) {
+      const float d = sD[j];
+      dcand[((size_t)b * C + j) * ld_dcand + c] = d * u;
+      du = fmaf(d, cand[((size_t)b * C + j) * ld_cand + c], du);
+    }
+    duser[(size_t)b * N + c] = du;
+  }
+}
+
+__global__ __launch_bounds__(256) void score_eval_kernel(const float* __restrict__ news, int ld_news,
+                                                         const int32_t* __restrict__ cand_ids,
+                                                         const int32_t* __restrict__ imp_of,
+                                                         const float* __restrict__ user, int ld_user,
+                                                         float* __restrict__ score, int n_cand, int N) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= n_cand) return;
+  const float* nr = news + (size_t)cand_ids[i] * ld_news;
+  const float* u = user + (size_t)imp_of[i] * ld_user;
+  float p = 0.f;
+  for (int c = lane; c < N; c += 64) p = fmaf(nr[c], u[c], p);
+  p = wave_sum(p);
+  if (lane == 0) score[i] = p;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 standalone row gather / scatter-add
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gather_fwd_kernel(const T* __restrict__ table, int ld_table,
+                                                         const int32_t* __restrict__ ids, int n_ids, int ids_stride,
+                                                         int cols, float* __restrict__ out, int ld_out) {
+  // one wave per row, 4 rows per workgroup; lanes stride the row 16 bytes at a time
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= n_ids) return;
+  const T* src = table + (size_t)ids[(size_t)r * ids_stride] * ld_table;
+  float* dst = out + (size_t)r * ld_out;
+  constexpr int CH = 16 / (int)sizeof(T);
+  const bool vec = (cols % CH == 0) && (ld_table % CH == 0) && (ld_out % 4 == 0) &&
+                   (((uintptr_t)table | (uintptr_t)out) & 15) == 0;
+  if (vec) {
+    for (int c = lane * CH; c < cols; c += 64 * CH) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(src + c);
+      if (sizeof(T) == 4) {
+        *reinterpret_cast<uint4*>(dst + c) = raw;
+      } else {
+        const bf16_t* h = reinterpret_cast<const bf16_t*>(&raw);
+        f32x4 lo = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        f32x4 hi = {(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+        *reinterpret_cast<f32x4*>(dst + c) = lo;
+        *reinterpret_cast<f32x4*>(dst + c + 4) = hi;
+      }
+    }
+  } else {
+    for (int c = lane; c < cols; c += 64) dst[c] = (float)src[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict__ dout, int ld_dout,
+                                                         const int32_t* __restrict__ ids, int n_ids, int ids_stride,
+                                                         int cols, float* __restrict__ dtable, int ld_dtable) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= n_ids) return;
+  const int id = ids[(size_t)r * ids_stride];
+  if (id == 0) return;  // padding_idx
+  for (int c = lane; c < cols; c += 64) atomicAdd(dtable + (size_t)id * ld_dtable + c, dout[(size_t)r * ld_dout + c]);
+}
+
+// ------------------------------------------------------------------------------------------
+// parameter packing
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_pad_kernel(const float* __restrict__ src, int rows, int cols, int ld_src, T* __restrict__ dst,
+                                int ld_dst, int transpose) {
+  const int drows = transpose ? cols : rows;
+  const size_t total = (size_t)drows * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld_dst), c = (int)(i - (size_t)r * ld_dst);
+    float v = 0.f;
+    if (!transpose) {
+      if (c < cols) v = src[(size_t)r * ld_src + c];
+    } else {
+      if (c < rows) v = src[(size_t)c * ld_src + r];
+    }
+    dst[i] = (T)v;
+  }
+}
+
+template <typename T>
+__global__ void pack_conv_w_kernel(const float* __restrict__ w, int N, int D, T* __restrict__ dst, int Dp) {
+  const size_t total = (size_t)N * 3 * Dp;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / (3 * Dp)), r = (int)(i - (size_t)n * 3 * Dp), tap = r / Dp, d = r - tap * Dp;
+    dst[i] = (T)(d < D ? w[((size_t)n * D + d) * 3 + tap] : 0.f);
+  }
+}
+
+__global__ void unpack_conv_dw_kernel(const float* __restrict__ dwp, int N, int D, int Dp, float* __restrict__ dw) {
+  const size_t total = (size_t)N * D * 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / (3 * D)), r = (int)(i - (size_t)n * 3 * D), d = r / 3, tap = r - d * 3;
+    dw[i] = dwp[(size_t)n * 3 * Dp + tap * Dp + d];
+  }
+}
+
+// fp32 rows (stride ld_src) -> dtype rows (stride ld_dst, zero padded)
+template <typename T>
+__global__ void cast_rows_kernel(const float* __restrict__ src, int ld_src, T* __restrict__ dst, int ld_dst, int rows,
+                                 int cols) {
+  const size_t total = (size_t)rows * ld_dst;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / ld_dst;
+    const int c = (int)(i - r * ld_dst);
+    dst[i] = (T)(c < cols ? src[r * ld_src + c] : 0.f);
+  }
+}
+
+__global__ void dropout_mask_kernel(float* __restrict__ out, uint32_t count, uint32_t key, uint32_t thresh) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x)
+    out[i] = (thresh == 0 || nr_keep(key, i, thresh)) ? 1.f : 0.f;
+}
+
+inline int grid_for(size_t total, int block = 256, int cap = 256 * 16) {
+  size_t g = (total + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > (size_t)cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+// ---- launchers used by nr_api.hip ---------------------------------------------------------
+int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
+                            float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s) {
+  NR_CHECK_ARG(L >= 1 && L <= 64, "additive_pool: L=%d must be in [1, 64]", L);
+  if (dtype == NR_BF16)
+    hipLaunchKernelGGL(pool_fwd_kernel<bf16_t>, dim3(n), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)e, w2, b2, mask, alpha, out, ld_out, L, N, q);
+  else
+    hipLaunchKernelGGL(pool_fwd_kernel<float>, dim3(n), dim3(256), 0, s, (const float*)x, (const float*)e, w2, b2, mask, alpha, out, ld_out, L, N, q);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_pool_partial_rows(int n) { return (n + POOL_SPB - 1) / POOL_SPB; }
+
+int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float* w2, const float* alpha, const float* g,
+                            int ld_g, void* dpre, float* partial, float* dw2, float* db2, int n, int L, int N, int q,
+                            hipStream_t s) {
+  NR_CHECK_ARG(L >= 1 && L <= 64, "additive_pool: L=%d must be in [1, 64]", L);
+  NR_CHECK_ARG(q <= 1024, "additive_pool: q=%d must be <= 1024", q);
+  const int nb = nr_pool_partial_rows(n);
+  if (dtype == NR_BF16)
+    hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)e, w2, alpha, g, ld_g, (bf16_t*)dpre, partial, n, L, N, q);
+  else
+    hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)e, w2, alpha, g, ld_g, (float*)dpre, partial, n, L, N, q);
+  NR_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_kernel, dim3((q + 63) / 64), dim3(256), 0, s, partial, nb, q, q + 1, dw2);
+  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, partial + q, nb, 1, q + 1, db2);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_launch_cast_rows(int dtype, const float* src, int ld_src, void* dst, int ld_dst, int rows, int cols, hipStream_t s) {
+  const size_t total = (size_t)rows * ld_dst;
+  if (dtype == NR_BF16)
+    hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, src, ld_src, (bf16_t*)dst, ld_dst, rows, cols);
+  else
+    hipLaunchKernelGGL(cast_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src, ld_src, (float*)dst, ld_dst, rows, cols);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+extern "C" {
+
+int nr_cast_pad(const float* src, int rows, int cols, int ld_src, void* dst, int ld_dst, int dtype, int transpose,
+                nr_stream_t stream) {
+  NR_CHECK_ARG(src && dst && rows > 0 && cols > 0, "cast_pad: null/empty");
+  NR_CHECK_ARG(ld_dst >= (transpose ? rows : cols) && ld_src >= cols, "cast_pad: leading dimensions too small");
+  const size_t total = (size_t)(transpose ? cols : rows) * ld_dst;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NR_BF16)
+    hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, src, rows, cols, ld_src, (bf16_t*)dst, ld_dst, transpose);
+  else
+    hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src, rows, cols, ld_src, (float*)dst, ld_dst, transpose);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_pack_conv_w(const float* w, int N, int D, void* dst, int Dp, int dtype, nr_stream_t stream) {
+  NR_CHECK_ARG(w && dst && N > 0 && D > 0 && Dp >= D, "pack_conv_w: bad arguments");
+  const size_t total = (size_t)N * 3 * Dp;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NR_BF16)
+    hipLaunchKernelGGL(pack_conv_w_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w, N, D, (bf16_t*)dst, Dp);
+  else
+    hipLaunchKernelGGL(pack_conv_w_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, N, D, (float*)dst, Dp);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_unpack_conv_dw(const float* dw_pack, int N, int D, int Dp, float* dw, nr_stream_t stream) {
+  NR_CHECK_ARG(dw_pack && dw && N > 0 && D > 0 && Dp >= D, "unpack_conv_dw: bad arguments");
+  hipLaunchKernelGGL(unpack_conv_dw_kernel, dim3(grid_for((size_t)N * D * 3)), dim3(256), 0, (hipStream_t)stream, dw_pack, N, D, Dp, dw);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_embed_gather_fwd(const void* table, int ld_table, int dtype, const int32_t* ids, int n_ids, int ids_stride,
+                        int cols, float* out, int ld_out, nr_stream_t stream) {
+  NR_CHECK_ARG(table && ids && out, "embed_gather_fwd: null pointer");
+  if (n_ids == 0) return NR_OK;
+  NR_CHECK_ARG(n_ids > 0 && cols > 0 && ids_stride >= 1, "embed_gather_fwd: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NR_BF16)
+    hipLaunchKernelGGL(gather_fwd_kernel<bf16_t>, dim3((n_ids + 3) / 4), dim3(256), 0, s, (const bf16_t*)table, ld_table, ids, n_ids, ids_stride, cols, out, ld_out);
+  else
+    hipLaunchKernelGGL(gather_fwd_kernel<float>, dim3((n_ids + 3) / 4), dim3(256), 0, s, (const float*)table, ld_table, ids, n_ids, ids_stride, cols, out, ld_out);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_embed_gather_bwd(const float* dout, int ld_dout, const int32_t* ids, int n_ids, int ids_stride, int cols,
+                        float* dtable, int ld_dtable, nr_stream_t stream) {
+  NR_CHECK_ARG(dout && ids && dtable, "embed_gather_bwd: null pointer");
+  if (n_ids == 0) return NR_OK;
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3((n_ids + 3) / 4), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, ids, n_ids, ids_stride, cols, dtable, ld_dtable);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_pad_blend_fwd(const float* x, const float* mask, const float* pad, void* out, int n, int L, int N, int dtype,
+                     nr_stream_t stream) {
+  NR_CHECK_ARG(x && out && n > 0 && L > 0 && N > 0, "pad_blend_fwd: null/empty");
+  NR_CHECK_ARG(mask == nullptr || pad != nullptr, "pad_blend_fwd: mask without pad_doc");
+  const size_t rows = (size_t)n * L;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NR_BF16)
+    hipLaunchKernelGGL(blend_fwd_kernel<bf16_t>, dim3(grid_for(rows * N)), dim3(256), 0, s, x, mask, pad, (bf16_t*)out, rows, N);
+  else
+    hipLaunchKernelGGL(blend_fwd_kernel<float>, dim3(grid_for(rows * N)), dim3(256), 0, s, x, mask, pad, (float*)out, rows, N);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_pad_blend_bwd(const void* dout, const float* mask, float* dx, float* dpad, int n, int L, int N, int dtype,
+                     nr_stream_t stream) {
+  NR_CHECK_ARG(dout && dx && n > 0 && L > 0 && N > 0, "pad_blend_bwd: null/empty");
+  const int rows = n * L, rpb = 64;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == NR_BF16)
+    hipLaunchKernelGGL(blend_bwd_kernel<bf16_t>, dim3((rows + rpb - 1) / rpb), dim3(256), 0, s, (const bf16_t*)dout, mask, dx, dpad, rows, N, rpb);
+  else
+    hipLaunchKernelGGL(blend_bwd_kernel<float>, dim3((rows + rpb - 1) / rpb), dim3(256), 0, s, (const float*)dout, mask, dx, dpad, rows, N, rpb);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_score_ce_fwd(const float* cand, int ld_cand, const float* user, const int64_t* label, float* score, float* loss,
+                    float* lossvec, int B, int C, int N, nr_stream_t stream) {
+  NR_CHECK_ARG(cand && user && label && score && loss && lossvec, "score_ce_fwd: null pointer");
+  NR_CHECK_ARG(B > 0 && C >= 1 && C <= 64 && N > 0, "score_ce_fwd: B=%d C=%d (1..64) N=%d", B, C, N);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(score_ce_fwd_kernel, dim3(B), dim3(64), 0, s, cand, ld_cand, user, label, score, lossvec, C, N);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, lossvec, B, loss);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_score_ce_bwd(const float* cand, int ld_cand, const float* user, const int64_t* label, const float* score,
+                    const float* gloss, const float* gscore, float* dcand, int ld_dcand, float* duser, int B, int C, int N,
+                    nr_stream_t stream) {
+  NR_CHECK_ARG(cand && user && label && score && dcand && duser, "score_ce_bwd: null pointer");
+  NR_CHECK_ARG(B > 0 && C >= 1 && C <= 64 && N > 0, "score_ce_bwd: B=%d C=%d (1..64) N=%d", B, C, N);
+  hipLaunchKernelGGL(score_ce_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cand, ld_cand, user, label, score, gloss, gscore, 1.0f / (float)B, dcand, ld_dcand, duser, C, N);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_score_eval(const float* news_vecs, int ld_news, const int32_t* cand_ids, const int32_t* imp_of, const float* user,
+                  int ld_user, float* score, int n_cand, int N, nr_stream_t stream) {
+  NR_CHECK_ARG(news_vecs && cand_ids && imp_of && user && score, "score_eval: null pointer");
+  if (n_cand == 0) return NR_OK;
+  hipLaunchKernelGGL(score_eval_kernel, dim3((n_cand + 3) / 4), dim3(256), 0, (hipStream_t)stream, news_vecs, ld_news, cand_ids, imp_of, user, ld_user, score, n_cand, N);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_dropout_mask(float* out, uint32_t count, float p, uint32_t seed, nr_stream_t stream) {
+  NR_CHECK_ARG(out != nullptr, "dropout_mask: null pointer");
+  if (count == 0) return NR_OK;
+  const DropCfg d = nr_make_drop(p, seed);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, out, count, d.key, d.thresh);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+"""Drop-in for the reference's src/model/NRMS.py (NewsEncoder / UserEncoder / Model)."""
+import torch
+from torch import nn
+
+from .. import ops
+from .model_utils import AttentionPooling, MultiHeadSelfAttention
+
+
+def _cd(args):
+    return getattr(args, "compute_dtype", "fp32")
+
+
+class NewsEncoder(nn.Module):
+    """src/model/NRMS.py:8-36: embed -> dropout -> MHSA -> dropout -> additive pooling."""
+
+    def __init__(self, args, embedding_matrix):
+        super().__init__()
+        self.embedding_matrix = embedding_matrix
+        self.drop_rate = args.drop_rate
+        self.dim_per_head = args.news_dim // args.num_attention_heads
+        assert args.news_dim == args.num_attention_heads * self.dim_per_head
+        self.multi_head_self_attn = MultiHeadSelfAttention(args.word_embedding_dim, args.num_attention_heads,
+                                                           self.dim_per_head, self.dim_per_head, compute_dtype=_cd(args))
+        self.attn = AttentionPooling(args.news_dim, args.news_query_vector_dim, compute_dtype=_cd(args))
+
+    def forward(self, x, mask=None):
+        """x: [n, word_num] token ids; mask: [n, word_num] or None -> [n, news_dim] fp32."""
+        p = self.drop_rate if self.training else 0.0
+        y = self.multi_head_self_attn.forward_gather(x, self.embedding_matrix.weight, mask=mask, p_in=p, p_out=p)
+        return self.attn(y, mask)
+
+
+class UserEncoder(nn.Module):
+    """src/model/NRMS.py:39-63."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.dim_per_head = args.news_dim // args.num_attention_heads
+        assert args.news_dim == args.num_attention_heads * self.dim_per_head
+        self.multi_head_self_attn = MultiHeadSelfAttention(args.news_dim, args.num_attention_heads, self.dim_per_head,
+                                                           self.dim_per_head, compute_dtype=_cd(args))
+        self.attn = AttentionPooling(args.news_dim, args.user_query_vector_dim, compute_dtype=_cd(args))
+        self.pad_doc = nn.Parameter(torch.empty(1, args.news_dim).uniform_(-1, 1)).type(torch.FloatTensor)
+
+    def forward(self, news_vecs, log_mask=None):
+        """news_vecs: [B, H, news_dim]; log_mask: [B, H] -> [B, news_dim] fp32."""
+        code = ops.dtype_code(_cd(self.args))
+        if self.args.user_log_mask:
+            x = ops.to_compute(news_vecs.float(), code)
+            y = self.multi_head_self_attn(x, mask=log_mask)
+            return self.attn(y, log_mask)
+        x = ops.pad_blend(news_vecs, log_mask, self.pad_doc, code)
+        y = self.multi_head_self_attn(x)
+        return self.attn(y)
+
+
+class Model(torch.nn.Module):
+    """src/model/NRMS.py:66-95.  Also accepts the positional (args, emb, n_cat, n_subcat) call of
+    src/main.py:64, which the reference class itself rejects."""
+
+    def __init__(self, args, embedding_matrix, *unused, **kwargs):
+        super().__init__()
+        self.args = args
+        pretrained_word_embedding = torch.from_numpy(embedding_matrix).float()
+        word_embedding = nn.Embedding.from_pretrained(pretrained_word_embedding, freeze=args.freeze_embedding, padding_idx=0)
+        self.news_encoder = NewsEncoder(args, word_embedding)
+        self.user_encoder = UserEncoder(args)
+        self.loss_fn = nn.CrossEntropyLoss()
+
+    def forward(self, history, history_mask, candidate, label):
+        """history [B, H, T] int32; history_mask [B, H] fp32; candidate [B, 1+K, T] int32; label [B] int64
+        -> (loss, score [B, 1+K])."""
+        a = self.args
+        B = candidate.shape[0]
+        C = 1 + a.npratio
+        cand = candidate.reshape(-1, a.num_words_title)
+        hist = history.reshape(-1, a.num_words_title)
+        # one encoder pass over candidates + history (the reference makes two, src/model/NRMS.py:87,90)
+        vecs = self.news_encoder(torch.cat([cand, hist], dim=0))
+        cand_vecs = vecs[: B * C].reshape(B, C, a.news_dim)
+        hist_vecs = vecs[B * C:].reshape(B, a.user_log_length, a.news_dim)
+        user_vec = self.user_encoder(hist_vecs, history_mask)
+        loss, score = ops.score_ce(cand_vecs, user_vec, label)
+        return loss, score

@@ -1,0 +1,68 @@
+"""Shared helpers for the GPU parity tests (CPU side: fixtures + the oracle as checker)."""
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from oracle import nr_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(tag):
+    z = np.load(os.path.join(GOLDEN, tag + ".npz"))
+    cfg = SimpleNamespace(**json.loads(str(z["cfg_json"])))
+    sd = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")}
+    return z, cfg, sd
+
+
+def table_key(tag):
+    return "news_encoder.embedding_matrix.weight" if tag.startswith("nrms") else "news_encoder.title_embeddings.weight"
+
+
+def build_model(tag, compute_dtype="fp32", train=False, device="cuda"):
+    """Our drop-in Model loaded with the reference's state_dict of a golden case."""
+    from newsrecommendation_amd.model import NAML, NRMS
+    z, cfg, sd = load_case(tag)
+    args = SimpleNamespace(**vars(cfg), compute_dtype=compute_dtype)
+    table = sd[table_key(tag)].numpy()
+    if tag.startswith("nrms"):
+        m = NRMS.Model(args, table)
+    else:
+        n_cat = sd["news_encoder.category_emb.weight"].shape[0] - 1 if "news_encoder.category_emb.weight" in sd else 0
+        n_sub = sd["news_encoder.subcategory_emb.weight"].shape[0] - 1 if "news_encoder.subcategory_emb.weight" in sd else 0
+        m = NAML.Model(args, table, n_cat, n_sub)
+    missing = m.load_state_dict(sd, strict=True)
+    m = m.to(device)
+    m.train(train)
+    return m, z, cfg, sd
+
+
+def batch_of(z, device="cuda"):
+    return tuple(torch.from_numpy(z[k]).to(device) for k in ("hist", "mask", "cand", "label"))
+
+
+def oracle_run(tag, z, cfg, sd, keep=None):
+    """Oracle forward + backward on CPU; returns (loss, score, grads dict)."""
+    fwd = O.nrms_forward if tag.startswith("nrms") else O.naml_forward
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    hist, mask, cand, label = (torch.from_numpy(z[k]) for k in ("hist", "mask", "cand", "label"))
+    loss, score = fwd(hist, mask, cand, label, sdo, cfg, keep=keep)
+    loss.backward()
+    return loss.detach(), score.detach(), {k: v.grad for k, v in sdo.items() if v.grad is not None}
+
+
+def max_err(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max()) if a.numel() else 0.0
+
+
+def assert_close(a, b, atol, rtol=0.0, name=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    if a.numel() == 0:
+        return
+    tol = atol + rtol * float(b.abs().max())
+    err = float((a - b).abs().max())
+    assert err <= tol, f"{name}: max|diff|={err:.3e} > {tol:.3e} (ref max {float(b.abs().max()):.3e})"

@@ -1,0 +1,92 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the golden fixtures produced by the
+reference and against the oracle on the same inputs.
+
+Tolerances (written here, as the task requires):
+  fp32 compute (exact-f32 MFMA): loss / score 1e-4 abs (north_star); gradients 2e-4 * max|grad| + 1e-6.
+  bf16 compute (bf16 MFMA operands + bf16 activations, fp32 accumulate): loss / score 3e-2 abs
+  (SURVEY §4 measured 4e-3..7e-3 drift for scores of magnitude ~1), gradients 6e-2 * max|grad|.
+"""
+import pytest
+import torch
+
+from helpers import assert_close, batch_of, build_model, oracle_run, table_key
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["nrms_tiny_pad", "nrms_tiny_mask", "naml_tiny_3view", "naml_tiny_title_mask",
+         "nrms_mind_pad", "nrms_mind_mask", "naml_mind_3view"]
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_fp32_forward_backward_vs_golden_and_oracle(tag):
+    m, z, cfg, sd = build_model(tag, "fp32")
+    hist, mask, cand, label = batch_of(z)
+    loss, score = m(hist, mask, cand, label)
+    loss.backward()
+    torch.cuda.synchronize()
+    # golden (reference outputs)
+    assert_close(loss, torch.from_numpy(z["loss"]), 1e-4, name="loss vs golden")
+    assert_close(score, torch.from_numpy(z["score"]), 1e-4, name="score vs golden")
+    # oracle: every gradient at full resolution
+    lo, so, go = oracle_run(tag, z, cfg, sd)
+    assert_close(loss, lo, 1e-4, name="loss vs oracle")
+    assert_close(score, so, 1e-4, name="score vs oracle")
+    checked = 0
+    for name, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        if name not in go:           # pad_doc under user_log_mask=True: unused in both
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        assert_close(p.grad, go[name], 1e-6, 2e-4, name="d" + name)
+        checked += 1
+    assert checked >= 8
+    tk = table_key(tag)
+    tp = dict(m.named_parameters())[tk]
+    if tp.requires_grad:             # padding_idx row receives no gradient
+        assert float(tp.grad[0].abs().max()) == 0.0
+    # golden gradient samples as well
+    step = int(z["sample_rows"])
+    grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    for k in z.files:
+        if k.startswith("grad::") and k[6:] in grads:
+            assert_close(grads[k[6:]], torch.from_numpy(z[k]), 1e-6, 2e-4, name=k)
+        elif k.startswith("gradrows::") and k[10:] in grads:
+            assert_close(grads[k[10:]][::step], torch.from_numpy(z[k]), 1e-6, 2e-4, name=k)
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_fp32_encoders_alone(tag):
+    """main.py:194,247 call news_encoder / user_encoder directly at eval time."""
+    m, z, cfg, sd = build_model(tag, "fp32")
+    hist, mask, cand, label = batch_of(z)
+    with torch.no_grad():
+        cv = m.news_encoder(cand.reshape(-1, cand.shape[-1]))
+        uv = m.user_encoder(torch.from_numpy(z["hist_vecs"]).cuda().reshape(hist.shape[0], cfg.user_log_length, -1), mask)
+    assert_close(cv, torch.from_numpy(z["cand_vecs"]), 1e-4, name="news_encoder")
+    assert_close(uv, torch.from_numpy(z["user_vec"]), 1e-4, name="user_encoder")
+
+
+@pytest.mark.parametrize("tag", ["nrms_mind_pad", "nrms_mind_mask", "naml_mind_3view"])
+def test_bf16_forward_backward_vs_oracle(tag):
+    m, z, cfg, sd = build_model(tag, "bf16")
+    hist, mask, cand, label = batch_of(z)
+    loss, score = m(hist, mask, cand, label)
+    loss.backward()
+    lo, so, go = oracle_run(tag, z, cfg, sd)
+    assert_close(loss, lo, 3e-2, name="loss")
+    assert_close(score, so, 3e-2, name="score")
+    for name, p in m.named_parameters():
+        if p.requires_grad and name in go:
+            assert_close(p.grad, go[name], 1e-5, 6e-2, name="d" + name)
+
+
+def test_state_dict_surface():
+    """Appendix A of SURVEY.md: checkpoint compatibility = same keys and shapes as the reference."""
+    for tag in ("nrms_mind_pad", "naml_mind_3view"):
+        m, z, cfg, sd = build_model(tag, "fp32", device="cpu")
+        ours = m.state_dict()
+        assert list(ours.keys()) == list(sd.keys())
+        for k in sd:
+            assert tuple(ours[k].shape) == tuple(sd[k].shape), k
