@@ -198,6 +198,14 @@ int nr_score_ce_bwd(const float* cand, int ld_cand, const float* user, const int
 int nr_score_eval(const float* news_vecs, int ld_news, const int32_t* cand_ids, const int32_t* imp_of,
                   const float* user, int ld_user, float* score, int n_cand, int N, nr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Per-kernel timing (measurement only).  While enabled, every kernel launch inside the library is
+ * bracketed by hipEventRecord on the launch stream.  nr_prof_collect waits for the recorded events,
+ * writes one line per label "label<TAB>launches<TAB>total_ms\n" into buf (host), clears the log and
+ * returns the number of bytes written (or a negative NR_ERR_* code).                          */
+int nr_prof_enable(int on);
+int nr_prof_collect(char* buf, size_t n);
+
 /* Test hook: materialise the dropout keep mask (1.0 / 0.0) for `count` element indices. */
 int nr_dropout_mask(float* out, uint32_t count, float p, uint32_t seed, nr_stream_t stream);
 

@@ -71,6 +71,8 @@ SIGNATURES = {
     "nr_score_ce_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "nr_score_eval": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
     "nr_dropout_mask": [_vp, _u32, _f, _u32, _vp],
+    "nr_prof_enable": [_i],
+    "nr_prof_collect": [C.c_char_p, C.c_size_t],
 }
 
 _lib = None
@@ -125,6 +127,23 @@ def last_error() -> str:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise RuntimeError(f"libnrhip {what} failed (code {rc}): {last_error()}")
+
+
+def prof_enable(on: bool) -> None:
+    check(lib().nr_prof_enable(int(on)), "nr_prof_enable")
+
+
+def prof_collect() -> dict:
+    """{label: (launches, total_ms)} of every kernel launched since the last collect (blocks on the events)."""
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().nr_prof_collect(buf, len(buf))
+    if n < 0:
+        raise RuntimeError(f"libnrhip nr_prof_collect failed: {last_error()}")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        label, cnt, ms = line.rsplit("\t", 2)
+        out[label] = (int(cnt), float(ms))
+    return out
 
 
 def ptr(t) -> int:

@@ -15,7 +15,52 @@ int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float
                             hipStream_t s);
 int nr_launch_cast_rows(int dtype, const float* src, int ld_src, void* dst, int ld_dst, int rows, int cols, hipStream_t s);
 
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 static thread_local char g_err[512] = "";
+
+// ---- per-kernel timing ---------------------------------------------------------------------
+bool g_nr_prof_on = false;
+namespace {
+struct ProfEntry { std::string label; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+std::vector<ProfEntry> g_prof_log;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+int prof_begin(const char* label, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfEntry e;
+  e.label = label;
+  if (!g_prof_pool.empty()) {
+    e.a = g_prof_pool.back().first; e.b = g_prof_pool.back().second;
+    g_prof_pool.pop_back();
+  } else {
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return -1;
+  }
+  (void)hipEventRecord(e.a, s);
+  g_prof_log.push_back(e);
+  return (int)g_prof_log.size() - 1;
+}
+}  // namespace
+NrProfScope::NrProfScope(const char* label, hipStream_t s) : idx(-1), stream(s) {
+  if (g_nr_prof_on) idx = prof_begin(label, s);
+}
+NrProfScope::NrProfScope(hipStream_t s, const char* fmt, ...) : idx(-1), stream(s) {
+  if (!g_nr_prof_on) return;
+  char buf[192];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  idx = prof_begin(buf, s);
+}
+NrProfScope::~NrProfScope() {
+  if (idx < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (idx < (int)g_prof_log.size()) (void)hipEventRecord(g_prof_log[idx].b, stream);
+}
 
 void nr_set_error(const char* fmt, ...) {
   va_list ap;
@@ -75,7 +120,42 @@ static int mhsa_check(const nr_mhsa_desc* d) {
 
 extern "C" {
 
-int nr_version(void) { return 100; }
+int nr_version(void) { return 101; }
+
+int nr_prof_enable(int on) {
+  g_nr_prof_on = on != 0;
+  return NR_OK;
+}
+
+int nr_prof_collect(char* buf, size_t n) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  std::map<std::string, std::pair<int, double>> agg;
+  std::vector<std::string> order;
+  for (auto& e : g_prof_log) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e.b) != hipSuccess || hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) {
+      nr_set_error("prof_collect: event query failed for %s", e.label.c_str());
+      return -NR_ERR_HIP;
+    }
+    if (!agg.count(e.label)) order.push_back(e.label);
+    auto& a = agg[e.label];
+    a.first += 1;
+    a.second += ms;
+    g_prof_pool.emplace_back(e.a, e.b);
+  }
+  g_prof_log.clear();
+  size_t off = 0;
+  for (auto& l : order) {
+    char line[256];
+    int w = snprintf(line, sizeof(line), "%s\t%d\t%.6f\n", l.c_str(), agg[l].first, agg[l].second);
+    if (buf && off + (size_t)w < n) {
+      memcpy(buf + off, line, (size_t)w);
+      off += (size_t)w;
+    }
+  }
+  if (buf && n) buf[off < n ? off : n - 1] = 0;
+  return (int)off;
+}
 
 int nr_last_error(char* buf, size_t n) {
   if (buf && n) {

@@ -251,6 +251,7 @@ int nr_launch_attn(bool bwd, int dtype, const void* qkv, const float* mask, void
   a.HG = hg;
   a.scale = 1.0f / sqrtf((float)d_head);
   a.drop = drop;
+  NrProfScope ps(stream, "attn_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? "bwd" : "fwd", dtype == NR_BF16 ? "bf16" : "f32", n, L, heads, d_head);
   if (dtype == NR_BF16) return launch_attn_d<bf16_t>(bwd, d_head, a, stream);
   return launch_attn_d<float>(bwd, d_head, a, stream);
 }

@@ -34,6 +34,16 @@ void nr_set_error(const char* fmt, ...);
   } while (0)
 #define NR_CHECK_LAUNCH() NR_CHECK_HIP(hipGetLastError())
 
+// ---- per-kernel timing scope (host); no-op unless nr_prof_enable(1) ----------------------
+struct NrProfScope {
+  int idx;
+  hipStream_t stream;
+  NrProfScope(const char* label, hipStream_t s);
+  NrProfScope(hipStream_t s, const char* fmt, ...);
+  ~NrProfScope();
+};
+extern bool g_nr_prof_on;
+
 static inline int nr_elt_size(int dtype) { return dtype == NR_BF16 ? 2 : 4; }
 // K granule of one 16-byte chunk in elements
 static inline int nr_chunk(int dtype) { return dtype == NR_BF16 ? 8 : 4; }

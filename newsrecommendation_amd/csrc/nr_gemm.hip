@@ -484,6 +484,7 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
   NR_CHECK_ARG(K % ch == 0 && ldb % ch == 0 && A.ld % ch == 0, "gemm_nt: K=%d ldb=%d lda=%d must be multiples of %d", K, ldb, A.ld, ch);
   NR_CHECK_ARG(((uintptr_t)A.base & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_nt: operands must be 16-byte aligned");
   if (epi != EPI_SCATTER) NR_CHECK_ARG(ep.ldc % 4 == 0 && ((uintptr_t)ep.C & 15) == 0, "gemm_nt: output ld %d / alignment", ep.ldc);
+  NrProfScope ps(stream, "gemm_nt[%s,rows=%d,epi=%d,M=%d,N=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", A.kind, epi, M, N, K);
   return dtype == NR_BF16 ? launch_nt_d<bf16_t>(A, B, ldb, M, N, K, epi, ep, stream)
                           : launch_nt_d<float>(A, B, ldb, M, N, K, epi, ep, stream);
 }
@@ -495,6 +496,7 @@ int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float
   NR_CHECK_ARG(N % ch == 0 && K % ch == 0 && ldc % ch == 0 && A.ld % ch == 0, "gemm_tn: N=%d K=%d ldc=%d lda=%d must be multiples of %d",
                N, K, ldc, A.ld, ch);
   NR_CHECK_ARG(((uintptr_t)A.base & 15) == 0 && ((uintptr_t)dC & 15) == 0, "gemm_tn: operands must be 16-byte aligned");
+  NrProfScope ps(stream, "gemm_tn[%s,rows=%d,M=%d,N=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", A.kind, M, N, K);
   return dtype == NR_BF16 ? launch_tn_d<bf16_t>(dC, ldc, A, dW, ldw, db, M, N, K, Nstore, Kstore, stream)
                           : launch_tn_d<float>(dC, ldc, A, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
 }

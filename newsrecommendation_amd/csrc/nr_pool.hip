@@ -365,6 +365,7 @@ inline int grid_for(size_t total, int block = 256, int cap = 256 * 16) {
 int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
                             float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s) {
   NR_CHECK_ARG(L >= 1 && L <= 64, "additive_pool: L=%d must be in [1, 64]", L);
+  NrProfScope ps(s, "pool_core_fwd[n=%d,L=%d,N=%d,q=%d]", n, L, N, q);
   if (dtype == NR_BF16)
     hipLaunchKernelGGL(pool_fwd_kernel<bf16_t>, dim3(n), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)e, w2, b2, mask, alpha, out, ld_out, L, N, q);
   else
@@ -381,6 +382,7 @@ int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float
   NR_CHECK_ARG(L >= 1 && L <= 64, "additive_pool: L=%d must be in [1, 64]", L);
   NR_CHECK_ARG(q <= 1024, "additive_pool: q=%d must be <= 1024", q);
   const int nb = nr_pool_partial_rows(n);
+  NrProfScope ps(s, "pool_core_bwd[n=%d,L=%d,N=%d,q=%d]", n, L, N, q);
   if (dtype == NR_BF16)
     hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)e, w2, alpha, g, ld_g, (bf16_t*)dpre, partial, n, L, N, q);
   else
@@ -410,6 +412,7 @@ int nr_cast_pad(const float* src, int rows, int cols, int ld_src, void* dst, int
   NR_CHECK_ARG(ld_dst >= (transpose ? rows : cols) && ld_src >= cols, "cast_pad: leading dimensions too small");
   const size_t total = (size_t)(transpose ? cols : rows) * ld_dst;
   hipStream_t s = (hipStream_t)stream;
+  NrProfScope ps(s, "cast_pad[rows=%d,cols=%d]", rows, cols);
   if (dtype == NR_BF16)
     hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, src, rows, cols, ld_src, (bf16_t*)dst, ld_dst, transpose);
   else
@@ -466,6 +469,7 @@ int nr_pad_blend_fwd(const float* x, const float* mask, const float* pad, void* 
   NR_CHECK_ARG(mask == nullptr || pad != nullptr, "pad_blend_fwd: mask without pad_doc");
   const size_t rows = (size_t)n * L;
   hipStream_t s = (hipStream_t)stream;
+  NrProfScope ps(s, "pad_blend_fwd[n=%d,L=%d,N=%d]", n, L, N);
   if (dtype == NR_BF16)
     hipLaunchKernelGGL(blend_fwd_kernel<bf16_t>, dim3(grid_for(rows * N)), dim3(256), 0, s, x, mask, pad, (bf16_t*)out, rows, N);
   else
@@ -479,6 +483,7 @@ int nr_pad_blend_bwd(const void* dout, const float* mask, float* dx, float* dpad
   NR_CHECK_ARG(dout && dx && n > 0 && L > 0 && N > 0, "pad_blend_bwd: null/empty");
   const int rows = n * L, rpb = 64;
   hipStream_t s = (hipStream_t)stream;
+  NrProfScope ps(s, "pad_blend_bwd[n=%d,L=%d,N=%d]", n, L, N);
   if (dtype == NR_BF16)
     hipLaunchKernelGGL(blend_bwd_kernel<bf16_t>, dim3((rows + rpb - 1) / rpb), dim3(256), 0, s, (const bf16_t*)dout, mask, dx, dpad, rows, N, rpb);
   else
@@ -492,6 +497,7 @@ int nr_score_ce_fwd(const float* cand, int ld_cand, const float* user, const int
   NR_CHECK_ARG(cand && user && label && score && loss && lossvec, "score_ce_fwd: null pointer");
   NR_CHECK_ARG(B > 0 && C >= 1 && C <= 64 && N > 0, "score_ce_fwd: B=%d C=%d (1..64) N=%d", B, C, N);
   hipStream_t s = (hipStream_t)stream;
+  NrProfScope ps(s, "score_ce_fwd[B=%d,C=%d,N=%d]", B, C, N);
   hipLaunchKernelGGL(score_ce_fwd_kernel, dim3(B), dim3(64), 0, s, cand, ld_cand, user, label, score, lossvec, C, N);
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, lossvec, B, loss);
   NR_CHECK_LAUNCH();
@@ -503,6 +509,7 @@ int nr_score_ce_bwd(const float* cand, int ld_cand, const float* user, const int
                     nr_stream_t stream) {
   NR_CHECK_ARG(cand && user && label && score && dcand && duser, "score_ce_bwd: null pointer");
   NR_CHECK_ARG(B > 0 && C >= 1 && C <= 64 && N > 0, "score_ce_bwd: B=%d C=%d (1..64) N=%d", B, C, N);
+  NrProfScope ps((hipStream_t)stream, "score_ce_bwd[B=%d,C=%d,N=%d]", B, C, N);
   hipLaunchKernelGGL(score_ce_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cand, ld_cand, user, label, score, gloss, gscore, 1.0f / (float)B, dcand, ld_dcand, duser, C, N);
   NR_CHECK_LAUNCH();
   return NR_OK;
