@@ -1,0 +1,347 @@
+// MFMA attention core for sequences of L <= 32 tokens (the title level: 98 % of the attention work).
+//
+// One wave owns one (sequence, head) pair: a 32 x 32 score tile on v_mfma_f32_32x32x16_bf16
+// (or v_mfma_f32_32x32x2_f32 in the exact-fp32 mode).  The wave stages its head's Q, K, V (and
+// d(ctx)) rows in a private LDS region, zero padded to 32 x 32, in two images:
+//   row-major  [token][c]   -> operands of products that contract over the head dim c
+//   transposed [c][token]   -> B operands of products that contract over tokens
+// Products contracting over tokens take their A operand straight from the accumulators of the
+// previous product (column on the lane, rows in the 16 registers; the k order inside a step is
+// the accumulator's row order, and the transposed LDS image is read in the same order).
+// Scores are computed in BOTH orientations in the backward pass so that the softmax statistics
+// (per query row) are lane-local and dK / dV (sums over query rows) need no cross-lane traffic:
+//   S^T = K Q^T, dP^T = V G^T (lane = query i)  -> m_i, 1/Z_i, rd_i, dQ = dS K
+//   S   = Q K^T, dP   = G V^T (lane = key j)    -> dK = dS^T Q, dV = P^T G
+// Softmax is the reference's (src/model/model_utils.py:47-53): exp, key mask after exp, denominator
+// sum + 1e-8, evaluated in the stable form with the row max factored out.
+#include "nr_common.h"
+
+namespace {
+
+constexpr int AW = 4;  // waves per workgroup
+
+template <typename T> struct AT;
+template <> struct AT<bf16_t> { static constexpr int SW = 40; };  // LDS row stride (elements): 80 B
+template <> struct AT<float> { static constexpr int SW = 36; };   // 144 B
+
+struct AttnMArgs {
+  const void* qkv;    // [n*L, 3N]
+  const float* mask;  // [n, L] or null
+  void* y;            // fwd out [n*L, N]
+  const void* dy;     // bwd in
+  void* dqkv;         // bwd out [n*L, 3N]
+  int n, L, heads, d, N;
+  float scale;
+  DropCfg drop;
+};
+
+__device__ __forceinline__ int rowof(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// acc[row a][col b] += sum_c A[a][c] * B[b][c]; A, B row-major LDS images [32][SW]
+__device__ __forceinline__ void mm_rr(f32x16& acc, const bf16_t* A, const bf16_t* B, int lane) {
+  constexpr int SW = AT<bf16_t>::SW;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + r * SW + 16 * s + 8 * h);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + r * SW + 16 * s + 8 * h);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void mm_rr(f32x16& acc, const float* A, const float* B, int lane) {
+  constexpr int SW = AT<float>::SW;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[r * SW + 2 * s + h], B[r * SW + 2 * s + h], acc, 0, 0, 0);
+}
+
+// acc[row i][col c] += sum_j X[j][i] * Bt[c][j]; X = accumulator tile (col i on the lane, rows j in
+// the registers), Bt = transposed LDS image [32 c][SW] with the token index contiguous.
+__device__ __forceinline__ void mm_xt(f32x16& acc, const f32x16& x, const bf16_t* Bt, int lane) {
+  constexpr int SW = AT<bf16_t>::SW;
+  const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = (bf16_t)x[8 * s + e];
+    const bf16_t* bp = Bt + c * SW + 16 * s + 4 * h;
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(bp);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(bp + 8);
+    const bf16x8 b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void mm_xt(f32x16& acc, const f32x16& x, const float* Bt, int lane) {
+  constexpr int SW = AT<float>::SW;
+  const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[t], Bt[c * SW + rowof(t, h)], acc, 0, 0, 0);
+}
+
+// Stage one [L, d] head slice (row stride ld in global memory) as zero padded LDS images.
+// lane = (row r = lane & 31, part = lane >> 5); part p owns columns [16p, 16p + 16).
+template <typename T, bool ROWMAJOR, bool TRANSPOSED, bool DROP>
+__device__ __forceinline__ void stage_head(const T* __restrict__ src, size_t ld, int L, int d, T* sR, T* sT, int lane,
+                                           const DropCfg& drop, uint32_t eidx0, uint32_t erow) {
+  constexpr int SW = AT<T>::SW;
+  const int r = lane & 31, c0 = (lane >> 5) * 16;
+  T v[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int c = c0 + e;
+    float f = 0.f;
+    if (r < L && c < d) {
+      f = (float)src[(size_t)r * ld + c];
+      if (DROP && drop.thresh) f = nr_keep(drop.key, eidx0 + (uint32_t)r * erow + (uint32_t)c, drop.thresh) ? f * drop.scale : 0.f;
+    }
+    v[e] = (T)f;
+  }
+  if (ROWMAJOR) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sR[r * SW + c0 + e] = v[e];
+  }
+  if (TRANSPOSED) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sT[(c0 + e) * SW + r] = v[e];
+  }
+}
+
+// per-wave LDS carve
+template <typename T> struct WaveLds {
+  static constexpr int IMG = 32 * AT<T>::SW;  // elements of one image
+};
+
+// ------------------------------------------------------------------------------------------ forward
+template <typename T>
+__global__ __launch_bounds__(AW * 64) void attn_mfma_fwd_kernel(AttnMArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = WaveLds<T>::IMG;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  T* base = reinterpret_cast<T*>(smem) + (size_t)wid * 3 * IMG;
+  T* sQ = base;
+  T* sK = base + IMG;
+  T* sVt = base + 2 * IMG;
+  float* sMask = reinterpret_cast<float*>(reinterpret_cast<T*>(smem) + (size_t)AW * 3 * IMG) + wid * 32;
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  T* y = reinterpret_cast<T*>(a.y);
+  const int N = a.N, L = a.L, d = a.d;
+  const long total = (long)a.n * a.heads;
+  const int h2 = lane >> 5, li = lane & 31;
+
+  for (long p0 = (long)blockIdx.x * AW; p0 < total; p0 += (long)gridDim.x * AW) {
+    const long p = p0 + wid;
+    const bool active = p < total;
+    const int seq = active ? (int)(p / a.heads) : 0, head = active ? (int)(p % a.heads) : 0;
+    const size_t row0 = (size_t)seq * L;
+    if (active) {
+      const T* src = qkv + row0 * 3 * N + head * d;
+      stage_head<T, true, false, false>(src, 3 * N, L, d, sQ, nullptr, lane, a.drop, 0, 0);
+      stage_head<T, true, false, false>(src + N, 3 * N, L, d, sK, nullptr, lane, a.drop, 0, 0);
+      stage_head<T, false, true, false>(src + 2 * N, 3 * N, L, d, nullptr, sVt, lane, a.drop, 0, 0);
+      if (lane < 32) sMask[lane] = (lane < L) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
+    }
+    __syncthreads();
+    if (active) {
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      mm_rr(st, sK, sQ, lane);  // S^T[j][i]: rows j (registers), col i (lane)
+      float m = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] *= a.scale;
+        if (rowof(r, h2) < L) m = fmaxf(m, st[r]);
+      }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = rowof(r, h2);
+        const float e = (j < L) ? __expf(st[r] - m) * sMask[j] : 0.f;
+        st[r] = e;
+        sum += e;
+      }
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / (sum + 1e-8f * __expf(-m));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] *= inv;
+      f32x16 ctx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+      mm_xt(ctx, st, sVt, lane);  // ctx[i][c]: rows i (registers), col c (lane)
+      if (li < d) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = rowof(r, h2);
+          if (i < L) {
+            float v = ctx[r];
+            const size_t off = (row0 + i) * N + head * d + li;
+            if (a.drop.thresh) v = nr_keep(a.drop.key, (uint32_t)off, a.drop.thresh) ? v * a.drop.scale : 0.f;
+            y[off] = (T)v;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+template <typename T>
+__global__ __launch_bounds__(AW * 64) void attn_mfma_bwd_kernel(AttnMArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int IMG = WaveLds<T>::IMG;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  T* base = reinterpret_cast<T*>(smem) + (size_t)wid * 7 * IMG;
+  T* sQ = base;
+  T* sK = base + IMG;
+  T* sV = base + 2 * IMG;
+  T* sG = base + 3 * IMG;
+  T* sQt = base + 4 * IMG;
+  T* sKt = base + 5 * IMG;
+  T* sGt = base + 6 * IMG;
+  float* sF = reinterpret_cast<float*>(reinterpret_cast<T*>(smem) + (size_t)AW * 7 * IMG) + wid * 128;
+  float* sMask = sF;        // [32]
+  float* sM = sF + 32;      // [32] row max
+  float* sInv = sF + 64;    // [32] 1/(Z)
+  float* sRd = sF + 96;     // [32] sum_j a_ij dA_ij
+  const T* qkv = reinterpret_cast<const T*>(a.qkv);
+  const T* dy = reinterpret_cast<const T*>(a.dy);
+  T* dqkv = reinterpret_cast<T*>(a.dqkv);
+  const int N = a.N, L = a.L, d = a.d;
+  const long total = (long)a.n * a.heads;
+  const int h2 = lane >> 5, li = lane & 31;
+  DropCfg nodrop;
+  nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
+
+  for (long p0 = (long)blockIdx.x * AW; p0 < total; p0 += (long)gridDim.x * AW) {
+    const long p = p0 + wid;
+    const bool active = p < total;
+    const int seq = active ? (int)(p / a.heads) : 0, head = active ? (int)(p % a.heads) : 0;
+    const size_t row0 = (size_t)seq * L;
+    if (active) {
+      const T* src = qkv + row0 * 3 * N + head * d;
+      stage_head<T, true, true, false>(src, 3 * N, L, d, sQ, sQt, lane, nodrop, 0, 0);
+      stage_head<T, true, true, false>(src + N, 3 * N, L, d, sK, sKt, lane, nodrop, 0, 0);
+      stage_head<T, true, false, false>(src + 2 * N, 3 * N, L, d, sV, nullptr, lane, nodrop, 0, 0);
+      stage_head<T, true, true, true>(dy + row0 * N + head * d, N, L, d, sG, sGt, lane, a.drop,
+                                      (uint32_t)(row0 * N + head * d), (uint32_t)N);
+      if (lane < 32) sMask[lane] = (lane < L) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
+    }
+    __syncthreads();
+    f32x16 dst;  // dS^T (lane = query i)
+    if (active) {
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+      mm_rr(st, sK, sQ, lane);   // S^T[j][i]
+      mm_rr(dpt, sV, sG, lane);  // dP^T[j][i] = <V_j, G_i>
+      float m = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] *= a.scale;
+        if (rowof(r, h2) < L) m = fmaxf(m, st[r]);
+      }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sum = 0.f, rdu = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = rowof(r, h2);
+        const float e = (j < L) ? __expf(st[r] - m) * sMask[j] : 0.f;
+        st[r] = e;
+        sum += e;
+        rdu = fmaf(e, dpt[r], rdu);
+      }
+      sum += __shfl_xor(sum, 32, 64);
+      rdu += __shfl_xor(rdu, 32, 64);
+      const float inv = 1.f / (sum + 1e-8f * __expf(-m));
+      const float rd = rdu * inv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r] = st[r] * inv * (dpt[r] - rd);
+      if (lane < 32) {
+        sM[lane] = m;
+        sInv[lane] = inv;
+        sRd[lane] = rd;
+      }
+    }
+    __syncthreads();
+    if (active) {
+      // dQ[i][c] = scale * sum_j dS[i][j] K[j][c]
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+      mm_xt(dq, dst, sKt, lane);
+      // second orientation: lane = key j, registers = query rows i
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      mm_rr(s, sQ, sK, lane);   // S[i][j]
+      mm_rr(dp, sG, sV, lane);  // dP[i][j]
+      const float mj = sMask[li];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = rowof(r, h2);
+        const float pij = __expf(s[r] * a.scale - sM[i]) * mj * sInv[i];  // rows i >= L: multiplied by zero operands below
+        s[r] = pij;                                                      // P[i][j]
+        dp[r] = pij * (dp[r] - sRd[i]);                                  // dS[i][j]
+      }
+      f32x16 dk, dv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+      mm_xt(dk, dp, sQt, lane);  // dK[j][c] = sum_i dS[i][j] Q[i][c]   (Q rows >= L are zero)
+      mm_xt(dv, s, sGt, lane);   // dV[j][c] = sum_i P[i][j] G[i][c]    (G rows >= L are zero)
+      if (li < d) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int t = rowof(r, h2);
+          if (t < L) {
+            T* op = dqkv + (row0 + t) * 3 * N + head * d + li;
+            op[0] = (T)(dq[r] * a.scale);
+            op[N] = (T)(dk[r] * a.scale);
+            op[2 * N] = (T)dv[r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+int launch_t(bool bwd, const AttnMArgs& a, hipStream_t stream) {
+  const long total = (long)a.n * a.heads;
+  long blocks = (total + AW - 1) / AW;
+  const size_t img = (size_t)WaveLds<T>::IMG * sizeof(T);
+  const size_t smem = bwd ? AW * (7 * img + 128 * sizeof(float)) : AW * (3 * img + 32 * sizeof(float));
+  const long cap = 256L * (bwd ? 2 : 8) * 2;
+  if (blocks > cap) blocks = cap;
+  if (bwd) {
+    auto k = attn_mfma_bwd_kernel<T>;
+    NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
+  } else {
+    auto k = attn_mfma_fwd_kernel<T>;
+    NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
+  }
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+}  // namespace
+
+bool nr_attn_mfma_supported(int L, int d_head) { return L >= 1 && L <= 32 && d_head >= 1 && d_head <= 32; }
+
+int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask, void* y, const void* dy, void* dqkv, int n,
+                        int L, int heads, int d_head, const DropCfg& drop, hipStream_t stream) {
+  NR_CHECK_ARG(nr_attn_mfma_supported(L, d_head), "attn_mfma: L=%d d_head=%d unsupported", L, d_head);
+  AttnMArgs a;
+  a.qkv = qkv; a.mask = mask; a.y = y; a.dy = dy; a.dqkv = dqkv;
+  a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;
+  a.scale = 1.0f / sqrtf((float)d_head);
+  a.drop = drop;
+  NrProfScope ps(stream, "attn_mfma_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? "bwd" : "fwd", dtype == NR_BF16 ? "bf16" : "f32", n, L, heads, d_head);
+  return dtype == NR_BF16 ? launch_t<bf16_t>(bwd, a, stream) : launch_t<float>(bwd, a, stream);
+}
