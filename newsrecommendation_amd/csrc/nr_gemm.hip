@@ -22,11 +22,10 @@ template <typename T> struct TileCfg {
   static constexpr int RPC = BM / CH;             // rows per permutation class (TN staging)
   static constexpr size_t STAGE_BYTES = (size_t)2 * 2 * BM * SK * sizeof(T);
 };
-constexpr size_t EPI_BYTES = (size_t)BM * SC * sizeof(float);
-constexpr size_t RED_BYTES = (size_t)16 * 128 * sizeof(float);
+constexpr size_t EPI_BYTES = (size_t)64 * SC * sizeof(float);   // epilogue tile: 64 rows at a time
 
 template <typename T> constexpr size_t smem_bytes() {
-  return (TileCfg<T>::STAGE_BYTES > EPI_BYTES ? TileCfg<T>::STAGE_BYTES : EPI_BYTES) + RED_BYTES;
+  return TileCfg<T>::STAGE_BYTES > EPI_BYTES ? TileCfg<T>::STAGE_BYTES : EPI_BYTES;
 }
 
 union Chunk {
@@ -78,6 +77,62 @@ __device__ __forceinline__ uint4 load_rows_chunk(const RowSrc& s, int m, int k, 
   c.u = *reinterpret_cast<const uint4*>(p);
   if (s.drop.thresh) drop_chunk<T>(c, s.drop, eidx, col, s.Dtrue);
   return c.u;
+}
+
+// Per-(thread, chunk slot) row context for the NT kernel: the row a staging slot reads is the same
+// for every k-step, so the id lookup (a dependent global load) is done once, not per step.
+template <typename T> struct RowCtx {
+  const T* p;     // dense / gather: row base ; im2col3: base of the gathered [Tlen, ld] block
+  uint32_t e0;    // dropout element index of column 0 of this row (im2col3: of the block)
+  int t;          // im2col3: token index inside the block
+  bool valid;
+};
+
+template <typename T, int KIND>
+__device__ __forceinline__ RowCtx<T> make_row_ctx(const RowSrc& s, int m, int M) {
+  RowCtx<T> c;
+  c.valid = m < M;
+  c.p = nullptr; c.e0 = 0; c.t = 0;
+  if (!c.valid) return c;
+  if (KIND == ROWS_DENSE) {
+    c.p = (const T*)s.base + (size_t)m * s.ld;
+    c.e0 = (uint32_t)m * (uint32_t)s.Dtrue;
+  } else if (KIND == ROWS_GATHER) {
+    const int id = s.ids[(size_t)m * s.ids_stride];
+    c.p = (const T*)s.base + (size_t)id * s.ld;
+    c.e0 = (uint32_t)m * (uint32_t)s.Dtrue;
+  } else {
+    const int blk = m / s.Tlen;
+    c.t = m - blk * s.Tlen;
+    const int id = s.ids[(size_t)blk * s.ids_stride];
+    c.p = (const T*)s.base + (size_t)id * s.Tlen * s.ld;
+    c.e0 = (uint32_t)(blk * s.Tlen) * (uint32_t)s.Dtrue;
+  }
+  return c;
+}
+
+template <typename T, int KIND>
+__device__ __forceinline__ uint4 load_ctx_chunk(const RowSrc& s, const RowCtx<T>& c, int k, int K) {
+  Chunk ch;
+  ch.u = make_uint4(0, 0, 0, 0);
+  if (!c.valid || k >= K) return ch.u;
+  const T* p;
+  uint32_t eidx;
+  int col = k;
+  if (KIND == ROWS_IM2COL3) {
+    const int tap = k / s.ld, d = k - tap * s.ld;
+    const int tt = c.t - 1 + tap;
+    if (tt < 0 || tt >= s.Tlen) return ch.u;
+    p = c.p + (size_t)tt * s.ld + d;
+    eidx = c.e0 + (uint32_t)tt * (uint32_t)s.Dtrue + (uint32_t)d;
+    col = d;
+  } else {
+    p = c.p + k;
+    eidx = c.e0 + (uint32_t)k;
+  }
+  ch.u = *reinterpret_cast<const uint4*>(p);
+  if (s.drop.thresh) drop_chunk<T>(ch, s.drop, eidx, col, s.Dtrue);
+  return ch.u;
 }
 
 // ---- MFMA fragments --------------------------------------------------------------------
@@ -179,11 +234,14 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __rest
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
 
   uint4 ra[TL::NCH], rb[TL::NCH];
+  RowCtx<T> rctx[TL::NCH];
+#pragma unroll
+  for (int i = 0; i < TL::NCH; ++i) rctx[i] = make_row_ctx<T, KIND>(A, m0 + (tid + i * NTHR) / TL::CPR, M);
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < TL::NCH; ++i) {
       const int c = tid + i * NTHR, row = c / TL::CPR, kc = (c % TL::CPR) * TL::CH;
-      ra[i] = load_rows_chunk<T, KIND>(A, m0 + row, k0 + kc, M, K);
+      ra[i] = load_ctx_chunk<T, KIND>(A, rctx[i], k0 + kc, K);
       uint4 z = make_uint4(0, 0, 0, 0);
       if (n0 + row < N && k0 + kc < K) z = *reinterpret_cast<const uint4*>(B + (size_t)(n0 + row) * ldb + k0 + kc);
       rb[i] = z;
@@ -216,27 +274,37 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __rest
     __syncthreads();
   }
 
-  // accumulators -> fp32 LDS tile (bias / tanh applied here, column is lane-constant)
+  // accumulators -> fp32 LDS tile, 64 rows at a time (bias / tanh applied here, column is lane-constant),
+  // then row-contiguous 16-byte stores / atomics.
+  float bv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int col = wn * 64 + j * 16 + (lane & 15);
-    float bv = 0.f;
-    if (EPI == EPI_STORE && ep.bias != nullptr && n0 + col < N) bv = ep.bias[n0 + col];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        float v = acc[i][j][r] + bv;
-        if (EPI == EPI_STORE && ep.act_tanh) v = tanhf(v);
-        sC[row * SC + col] = v;
-      }
+    bv[j] = (EPI == EPI_STORE && ep.bias != nullptr && n0 + col < N) ? ep.bias[n0 + col] : 0.f;
   }
-  __syncthreads();
-  for (int u = tid; u < BM * (BN / 4); u += NTHR) {
-    const int row = u / (BN / 4), c0 = (u % (BN / 4)) * 4;
-    const int m = m0 + row, n = n0 + c0;
-    if (m < M && n < N) emit4<EPI>(ep, m, n, N, *reinterpret_cast<const f32x4*>(sC + row * SC + c0));
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[i][j][r] + bv[j];
+            if (EPI == EPI_STORE && ep.act_tanh) v = tanhf(v);
+            sC[(i * 16 + (lane >> 4) * 4 + r) * SC + col] = v;
+          }
+      }
+    }
+    __syncthreads();
+    for (int u = tid; u < 64 * (BN / 4); u += NTHR) {
+      const int row = u / (BN / 4), c0 = (u % (BN / 4)) * 4;
+      const int m = m0 + half * 64 + row, n = n0 + c0;
+      if (m < M && n < N) emit4<EPI>(ep, m, n, N, *reinterpret_cast<const f32x4*>(sC + row * SC + c0));
+    }
   }
 }
 
@@ -262,7 +330,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_kernel(const T* __restrict__ dC,
   T* sA = reinterpret_cast<T*>(smem);
   T* sB = sA + 2 * BM * TL::SK;
   float* sC = reinterpret_cast<float*>(smem);
-  float* sRed = reinterpret_cast<float*>(smem + (TL::STAGE_BYTES > EPI_BYTES ? TL::STAGE_BYTES : EPI_BYTES));
+  float* sRed = reinterpret_cast<float*>(smem);   // aliases the staging buffers after the main loop
 
   const int tn = blockIdx.x / tilesK, tk = blockIdx.x % tilesK;
   const int n0 = tn * BM, k0 = tk * BN;
@@ -355,7 +423,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_kernel(const T* __restrict__ dC,
     __syncthreads();
   }
 
-  // bias gradient: column sums of dC over this block's rows
+  // bias gradient: column sums of dC over this block's rows (sRed aliases the drained staging buffers)
   if (do_db) {
     if (IS_BF16) {
       const int nc = tid & 15, mp = tid >> 4;
@@ -366,36 +434,43 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_kernel(const T* __restrict__ dC,
 #pragma unroll
       for (int e = 0; e < TL::CH; ++e) sRed[g * 128 + nc * 4 + e] = colsum[e];
     }
+    __syncthreads();
+    if (tid < 128 && n0 + tid < Nstore) {
+      float sacc = 0.f;
+      constexpr int G = IS_BF16 ? 16 : 8;
+#pragma unroll
+      for (int g = 0; g < G; ++g) sacc += sRed[g * 128 + tid];
+      atomicAdd(db + n0 + tid, sacc);
+    }
+    __syncthreads();
   }
-  // accumulators -> epilogue tile in natural (n, k) order
+  // accumulators -> epilogue tile in natural (n, k) order, 64 output rows (n) at a time.  A wave's
+  // 64 permuted rows unpermute to rows spread over the whole tile, so every wave writes in both halves.
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int kl = unperm<T>(wn * 64 + j * 16 + (lane & 15));
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const int kl = unperm<T>(wn * 64 + j * 16 + (lane & 15));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int nl = unperm<T>(wm * 64 + i * 16 + (lane >> 4) * 4 + r);
-        sC[nl * SC + kl] = acc[i][j][r];
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nl = unperm<T>(wm * 64 + i * 16 + (lane >> 4) * 4 + r);
+          if ((nl >> 6) == half) sC[(nl & 63) * SC + kl] = acc[i][j][r];
+        }
+    }
+    __syncthreads();
+    for (int u = tid; u < 64 * (BN / 4); u += NTHR) {
+      const int row = u / (BN / 4), c0 = (u % (BN / 4)) * 4;
+      const int n = n0 + half * 64 + row, k = k0 + c0;
+      if (n < Nstore && k < Kstore) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * SC + c0);
+        float* dst = dW + (size_t)n * ldw + k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + e < Kstore) atomicAdd(dst + e, v[e]);
       }
-  }
-  __syncthreads();
-  if (do_db && tid < 128 && n0 + tid < Nstore) {
-    float s = 0.f;
-    constexpr int G = IS_BF16 ? 16 : 8;
-#pragma unroll
-    for (int g = 0; g < G; ++g) s += sRed[g * 128 + tid];
-    atomicAdd(db + n0 + tid, s);
-  }
-  for (int u = tid; u < BM * (BN / 4); u += NTHR) {
-    const int row = u / (BN / 4), c0 = (u % (BN / 4)) * 4;
-    const int n = n0 + row, k = k0 + c0;
-    if (n < Nstore && k < Kstore) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * SC + c0);
-      float* dst = dW + (size_t)n * ldw + k;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (k + e < Kstore) atomicAdd(dst + e, v[e]);
     }
   }
 }
