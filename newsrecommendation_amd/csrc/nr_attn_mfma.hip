@@ -31,6 +31,7 @@ struct AttnMArgs {
   const void* dy;     // bwd in
   void* dqkv;         // bwd out [n*L, 3N]
   int n, L, heads, d, N;
+  int vec;            // 1: d % 4 == 0 and all head slices are 4-element aligned -> vector staging / stores
   float scale;
   DropCfg drop;
 };
@@ -108,6 +109,72 @@ __device__ __forceinline__ void stage_head(const T* __restrict__ src, size_t ld,
   }
 }
 
+
+// 4-element vectors (8 B bf16 / 16 B f32) for the staging / store paths
+template <typename T> struct V4;
+template <> struct V4<bf16_t> { using type = bf16x4; };
+template <> struct V4<float> { using type = f32x4; };
+
+// Vector form of stage_head: a head slice row is d/4 chunks of 4 elements; lane (r, part) owns chunks
+// part, part+2, part+4, part+6.  Needs d % 4 == 0 and a 4-element aligned slice (checked by the caller).
+template <typename T, bool ROWMAJOR, bool TRANSPOSED, bool DROP>
+__device__ __forceinline__ void stage_head_v(const T* __restrict__ src, size_t ld, int L, int d, T* sR, T* sT, int lane,
+                                             const DropCfg& drop, uint32_t eidx0, uint32_t erow) {
+  constexpr int SW = AT<T>::SW;
+  using VT = typename V4<T>::type;
+  const int r = lane & 31, part = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * (2 * q + part);
+    VT v = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+    if (r < L && c < d) {
+      v = *reinterpret_cast<const VT*>(src + (size_t)r * ld + c);
+      if (DROP && drop.thresh) {
+        const uint32_t e0 = eidx0 + (uint32_t)r * erow + (uint32_t)c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = nr_keep(drop.key, e0 + e, drop.thresh) ? (T)((float)v[e] * drop.scale) : (T)0.f;
+      }
+    }
+    if (ROWMAJOR) *reinterpret_cast<VT*>(sR + r * SW + c) = v;
+    if (TRANSPOSED) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sT[(c + e) * SW + r] = v[e];
+    }
+  }
+}
+
+// accumulator tile (col c on the lane, rows in the registers) -> LDS image [row][c] of type T
+template <typename T>
+__device__ __forceinline__ void acc_to_lds(const f32x16& acc, float mul, T* sO, int lane) {
+  constexpr int SW = AT<T>::SW;
+  const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sO[rowof(r, h) * SW + c] = (T)(acc[r] * mul);
+}
+
+// LDS image [row][c] -> global rows (stride ld), 4 elements at a time; optional dropout by element index
+template <typename T, bool DROP>
+__device__ __forceinline__ void lds_to_global_v(const T* sO, T* __restrict__ dst, size_t ld, int L, int d, int lane,
+                                                const DropCfg& drop, uint32_t eidx0, uint32_t erow) {
+  constexpr int SW = AT<T>::SW;
+  using VT = typename V4<T>::type;
+  const int r = lane & 31, part = lane >> 5;
+  if (r >= L) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * (2 * q + part);
+    if (c < d) {
+      VT v = *reinterpret_cast<const VT*>(sO + r * SW + c);
+      if (DROP && drop.thresh) {
+        const uint32_t e0 = eidx0 + (uint32_t)r * erow + (uint32_t)c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = nr_keep(drop.key, e0 + e, drop.thresh) ? (T)((float)v[e] * drop.scale) : (T)0.f;
+      }
+      *reinterpret_cast<VT*>(dst + (size_t)r * ld + c) = v;
+    }
+  }
+}
+
 // per-wave LDS carve
 template <typename T> struct WaveLds {
   static constexpr int IMG = 32 * AT<T>::SW;  // elements of one image
@@ -129,6 +196,7 @@ __global__ __launch_bounds__(AW * 64) void attn_mfma_fwd_kernel(AttnMArgs a) {
   const int N = a.N, L = a.L, d = a.d;
   const long total = (long)a.n * a.heads;
   const int h2 = lane >> 5, li = lane & 31;
+  const bool vec = a.vec != 0;
 
   for (long p0 = (long)blockIdx.x * AW; p0 < total; p0 += (long)gridDim.x * AW) {
     const long p = p0 + wid;
@@ -137,9 +205,15 @@ __global__ __launch_bounds__(AW * 64) void attn_mfma_fwd_kernel(AttnMArgs a) {
     const size_t row0 = (size_t)seq * L;
     if (active) {
       const T* src = qkv + row0 * 3 * N + head * d;
-      stage_head<T, true, false, false>(src, 3 * N, L, d, sQ, nullptr, lane, a.drop, 0, 0);
-      stage_head<T, true, false, false>(src + N, 3 * N, L, d, sK, nullptr, lane, a.drop, 0, 0);
-      stage_head<T, false, true, false>(src + 2 * N, 3 * N, L, d, nullptr, sVt, lane, a.drop, 0, 0);
+      if (vec) {
+        stage_head_v<T, true, false, false>(src, 3 * N, L, d, sQ, nullptr, lane, a.drop, 0, 0);
+        stage_head_v<T, true, false, false>(src + N, 3 * N, L, d, sK, nullptr, lane, a.drop, 0, 0);
+        stage_head_v<T, false, true, false>(src + 2 * N, 3 * N, L, d, nullptr, sVt, lane, a.drop, 0, 0);
+      } else {
+        stage_head<T, true, false, false>(src, 3 * N, L, d, sQ, nullptr, lane, a.drop, 0, 0);
+        stage_head<T, true, false, false>(src + N, 3 * N, L, d, sK, nullptr, lane, a.drop, 0, 0);
+        stage_head<T, false, true, false>(src + 2 * N, 3 * N, L, d, nullptr, sVt, lane, a.drop, 0, 0);
+      }
       if (lane < 32) sMask[lane] = (lane < L) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
     }
     __syncthreads();
@@ -171,19 +245,26 @@ __global__ __launch_bounds__(AW * 64) void attn_mfma_fwd_kernel(AttnMArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
       mm_xt(ctx, st, sVt, lane);  // ctx[i][c]: rows i (registers), col c (lane)
-      if (li < d) {
+      if (!vec) {
+        if (li < d) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = rowof(r, h2);
-          if (i < L) {
-            float v = ctx[r];
-            const size_t off = (row0 + i) * N + head * d + li;
-            if (a.drop.thresh) v = nr_keep(a.drop.key, (uint32_t)off, a.drop.thresh) ? v * a.drop.scale : 0.f;
-            y[off] = (T)v;
+          for (int r = 0; r < 16; ++r) {
+            const int i = rowof(r, h2);
+            if (i < L) {
+              float v = ctx[r];
+              const size_t off = (row0 + i) * N + head * d + li;
+              if (a.drop.thresh) v = nr_keep(a.drop.key, (uint32_t)off, a.drop.thresh) ? v * a.drop.scale : 0.f;
+              y[off] = (T)v;
+            }
           }
         }
+      } else {
+        acc_to_lds<T>(ctx, 1.f, sQ, lane);   // sQ is dead after S^T (wave-private region)
       }
     }
+    __syncthreads();
+    if (active && vec)
+      lds_to_global_v<T, true>(sQ, y + row0 * N + head * d, N, L, d, lane, a.drop, (uint32_t)(row0 * N + head * d), (uint32_t)N);
     __syncthreads();
   }
 }
@@ -213,6 +294,7 @@ __global__ __launch_bounds__(AW * 64) void attn_mfma_bwd_kernel(AttnMArgs a) {
   const int N = a.N, L = a.L, d = a.d;
   const long total = (long)a.n * a.heads;
   const int h2 = lane >> 5, li = lane & 31;
+  const bool vec = a.vec != 0;
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
 
@@ -223,11 +305,19 @@ __global__ __launch_bounds__(AW * 64) void attn_mfma_bwd_kernel(AttnMArgs a) {
     const size_t row0 = (size_t)seq * L;
     if (active) {
       const T* src = qkv + row0 * 3 * N + head * d;
-      stage_head<T, true, true, false>(src, 3 * N, L, d, sQ, sQt, lane, nodrop, 0, 0);
-      stage_head<T, true, true, false>(src + N, 3 * N, L, d, sK, sKt, lane, nodrop, 0, 0);
-      stage_head<T, true, false, false>(src + 2 * N, 3 * N, L, d, sV, nullptr, lane, nodrop, 0, 0);
-      stage_head<T, true, true, true>(dy + row0 * N + head * d, N, L, d, sG, sGt, lane, a.drop,
-                                      (uint32_t)(row0 * N + head * d), (uint32_t)N);
+      if (vec) {
+        stage_head_v<T, true, true, false>(src, 3 * N, L, d, sQ, sQt, lane, nodrop, 0, 0);
+        stage_head_v<T, true, true, false>(src + N, 3 * N, L, d, sK, sKt, lane, nodrop, 0, 0);
+        stage_head_v<T, true, false, false>(src + 2 * N, 3 * N, L, d, sV, nullptr, lane, nodrop, 0, 0);
+        stage_head_v<T, true, true, true>(dy + row0 * N + head * d, N, L, d, sG, sGt, lane, a.drop,
+                                          (uint32_t)(row0 * N + head * d), (uint32_t)N);
+      } else {
+        stage_head<T, true, true, false>(src, 3 * N, L, d, sQ, sQt, lane, nodrop, 0, 0);
+        stage_head<T, true, true, false>(src + N, 3 * N, L, d, sK, sKt, lane, nodrop, 0, 0);
+        stage_head<T, true, false, false>(src + 2 * N, 3 * N, L, d, sV, nullptr, lane, nodrop, 0, 0);
+        stage_head<T, true, true, true>(dy + row0 * N + head * d, N, L, d, sG, sGt, lane, a.drop,
+                                        (uint32_t)(row0 * N + head * d), (uint32_t)N);
+      }
       if (lane < 32) sMask[lane] = (lane < L) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
     }
     __syncthreads();
@@ -267,9 +357,9 @@ __global__ __launch_bounds__(AW * 64) void attn_mfma_bwd_kernel(AttnMArgs a) {
       }
     }
     __syncthreads();
+    f32x16 dq, dk, dv;
     if (active) {
       // dQ[i][c] = scale * sum_j dS[i][j] K[j][c]
-      f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
       mm_xt(dq, dst, sKt, lane);
@@ -287,12 +377,11 @@ __global__ __launch_bounds__(AW * 64) void attn_mfma_bwd_kernel(AttnMArgs a) {
         s[r] = pij;                                                      // P[i][j]
         dp[r] = pij * (dp[r] - sRd[i]);                                  // dS[i][j]
       }
-      f32x16 dk, dv;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
       mm_xt(dk, dp, sQt, lane);  // dK[j][c] = sum_i dS[i][j] Q[i][c]   (Q rows >= L are zero)
       mm_xt(dv, s, sGt, lane);   // dV[j][c] = sum_i P[i][j] G[i][c]    (G rows >= L are zero)
-      if (li < d) {
+      if (!vec && li < d) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int t = rowof(r, h2);
@@ -303,6 +392,21 @@ __global__ __launch_bounds__(AW * 64) void attn_mfma_bwd_kernel(AttnMArgs a) {
             op[2 * N] = (T)dv[r];
           }
         }
+      }
+    }
+    if (vec) {
+      __syncthreads();   // every product has consumed the wave's images: reuse three of them as output tiles
+      if (active) {
+        acc_to_lds<T>(dq, a.scale, sQ, lane);
+        acc_to_lds<T>(dk, a.scale, sK, lane);
+        acc_to_lds<T>(dv, 1.f, sV, lane);
+      }
+      __syncthreads();
+      if (active) {
+        T* op = dqkv + row0 * 3 * N + head * d;
+        lds_to_global_v<T, false>(sQ, op, 3 * N, L, d, lane, nodrop, 0, 0);
+        lds_to_global_v<T, false>(sK, op + N, 3 * N, L, d, lane, nodrop, 0, 0);
+        lds_to_global_v<T, false>(sV, op + 2 * N, 3 * N, L, d, lane, nodrop, 0, 0);
       }
     }
     __syncthreads();
@@ -342,6 +446,8 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;
   a.scale = 1.0f / sqrtf((float)d_head);
   a.drop = drop;
+  const uintptr_t al = dtype == NR_BF16 ? 7 : 15;
+  a.vec = (d_head % 4 == 0) && (((uintptr_t)qkv | (uintptr_t)y | (uintptr_t)dy | (uintptr_t)dqkv) & al) == 0;
   NrProfScope ps(stream, "attn_mfma_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? "bwd" : "fwd", dtype == NR_BF16 ? "bf16" : "f32", n, L, heads, d_head);
   return dtype == NR_BF16 ? launch_t<bf16_t>(bwd, a, stream) : launch_t<float>(bwd, a, stream);
 }
