@@ -97,6 +97,11 @@ typedef struct {
   const void* w_qkv;  /* [3N, ldw] dtype: rows W_Q | W_K | W_V (nr_cast_pad of each)         */
   int ldw;
   const float* b_qkv; /* [3N] fp32 */
+  void* x_rows;       /* optional [n*L, ld_rows] dtype (ld_rows >= d_model rounded up to a chunk): with a gather
+                         source nr_mhsa_fwd stores the gathered + dropped-out rows X here and nr_mhsa_bwd reads
+                         them back as a dense operand of the weight-gradient GEMM (no second gather / RNG pass);
+                         NULL: backward regenerates X from (table, ids, seed_in).                            */
+  int ld_rows;
 } nr_mhsa_desc;
 
 /* qkv: [n*L, 3N] dtype (saved for backward); y: [n*L, N] dtype. */

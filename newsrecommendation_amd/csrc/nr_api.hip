@@ -176,6 +176,11 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
   EpiArgs ep = store_epi(qkv, 3 * N, d->dtype, d->b_qkv, 0);
+  if (d->x_rows != nullptr && d->src_kind == NR_SRC_GATHER) {
+    NR_CHECK_ARG(d->ld_rows >= Kp && d->ld_rows % nr_chunk(d->dtype) == 0, "mhsa_fwd: ld_rows=%d must cover %d", d->ld_rows, Kp);
+    ep.rows_out = d->x_rows;
+    ep.ld_rows_out = d->ld_rows;
+  }
   if ((rc = nr_launch_gemm_nt(d->dtype, A, d->w_qkv, d->ldw, M, 3 * N, Kp, EPI_STORE, ep, s))) return rc;
   return nr_launch_attn(false, d->dtype, qkv, d->mask, y, nullptr, nullptr, d->n, d->L, d->heads, d->d_head,
                         nr_make_drop(d->p_out, d->seed_out), s);
@@ -194,8 +199,13 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
   if ((rc = nr_launch_attn(true, d->dtype, qkv, d->mask, nullptr, dy, dqkv, d->n, d->L, d->heads, d->d_head,
                            nr_make_drop(d->p_out, d->seed_out), s)))
     return rc;
-  // dW_qkv[3N, d_model] += dQKV^T . X ; db += colsum(dQKV)
-  if ((rc = nr_launch_gemm_tn(d->dtype, dqkv, 3 * N, A, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model, s))) return rc;
+  // dW_qkv[3N, d_model] += dQKV^T . X ; db += colsum(dQKV).  X: the rows saved by the forward when present.
+  RowSrc Xs = A;
+  if (d->x_rows != nullptr && d->src_kind == NR_SRC_GATHER) {
+    NR_CHECK_ARG(d->ld_rows >= Kp, "mhsa_bwd: ld_rows=%d must cover %d", d->ld_rows, Kp);
+    Xs = dense_rows(d->x_rows, d->ld_rows, d->d_model);
+  }
+  if ((rc = nr_launch_gemm_tn(d->dtype, dqkv, 3 * N, Xs, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model, s))) return rc;
   if (dx != nullptr || dtable != nullptr) {
     NR_CHECK_ARG(w_qkv_t != nullptr && ldwt >= 3 * N, "mhsa_bwd: w_qkv_t [d_model, >=3N] needed for dx / dtable");
     RowSrc G = dense_rows(dqkv, 3 * N, 3 * N);

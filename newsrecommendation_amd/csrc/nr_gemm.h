@@ -39,6 +39,8 @@ struct EpiArgs {
   int ids_stride;
   int Dtrue;
   DropCfg drop;           // SCATTER: the forward's input dropout
+  void* rows_out;         // optional: the staged A rows (after gather / dropout), dtype, [M, ld_rows_out]
+  int ld_rows_out;
 };
 
 // C-level launchers (enqueue only).  dtype selects T.

@@ -7,6 +7,8 @@
 //   f32 : eight v_mfma_f32_16x16x4_f32 (sub-step e takes k = 8*(lane>>4)+e from both operands)
 // Global -> register -> LDS double buffering, one barrier per k-step.  The epilogue goes
 // through an fp32 LDS tile so that global stores / atomics are 16-byte, row-contiguous.
+#include <stdlib.h>
+
 #include "nr_gemm.h"
 
 namespace {
@@ -247,12 +249,15 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __rest
       rb[i] = z;
     }
   };
-  auto swrite = [&](int buf) {
+  const bool save_rows = (ep.rows_out != nullptr) && (tn == 0);
+  auto swrite = [&](int buf, int k0) {
 #pragma unroll
     for (int i = 0; i < TL::NCH; ++i) {
       const int c = tid + i * NTHR, row = c / TL::CPR, kc = (c % TL::CPR) * TL::CH;
       *reinterpret_cast<uint4*>(sA + buf * BM * TL::SK + row * TL::SK + kc) = ra[i];
       *reinterpret_cast<uint4*>(sB + buf * BN * TL::SK + row * TL::SK + kc) = rb[i];
+      if (save_rows && m0 + row < M && k0 + kc < K)
+        *reinterpret_cast<uint4*>((T*)ep.rows_out + (size_t)(m0 + row) * ep.ld_rows_out + k0 + kc) = ra[i];
     }
   };
 
@@ -264,13 +269,13 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __rest
 
   const int nk = (K + BK - 1) / BK;
   gload(0);
-  swrite(0);
+  swrite(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
     mma_tile_step<T>(acc, sA + cur * BM * TL::SK, sB + cur * BN * TL::SK, wm, wn, lane);
-    if (kt + 1 < nk) swrite(cur ^ 1);
+    if (kt + 1 < nk) swrite(cur ^ 1, (kt + 1) * BK);
     __syncthreads();
   }
 
@@ -475,6 +480,196 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_kernel(const T* __restrict__ dC,
   }
 }
 
+
+// =========================================================================================
+// TN v2 (bf16, dense operands): dW[N,K] += dC[M,N]^T X[M,K] without transposing writes.
+// Both operands are staged in LDS exactly as they lie in memory ([m][n] / [m][k], 16-byte
+// chunks, XOR-swizzled per row) and the MFMA fragments, which need 8 consecutive m for a fixed
+// column, are fetched with ds_read_b64_tr_b16 (a 4-row x 16-column block delivered column-major
+// to a 16-lane group).  Output tile 128 (n) x 160 (k) per workgroup, 32 rows of m per step.
+// The per-row chunk swizzles make every transposed read conflict-free (a 32-lane half covers
+// 8 rows x 32 B = all 64 banks once):
+//   dC tile, 256-B rows : chunk ^= 2*(row & 3) + 8*((row >> 3) & 1)
+//   X  tile, 320-B rows : chunk ^= 2*((row >> 3) & 1)   (rows are already skewed by 64 B)
+// =========================================================================================
+namespace tn2 {
+constexpr int TBN = 128, TBK = 160, TBM = 32;
+constexpr int SCW = TBK + 4;
+constexpr size_t STAGE = (size_t)2 * TBM * (TBN + TBK) * sizeof(bf16_t);   // 36,864 B
+constexpr size_t EPI = (size_t)64 * SCW * sizeof(float);                     // 41,984 B
+constexpr size_t SMEM = STAGE > EPI ? STAGE : EPI;
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ int swz_a(int row, int chunk) { return chunk ^ (2 * (row & 3) + 8 * ((row >> 3) & 1)); }
+__device__ __forceinline__ int swz_b(int row, int chunk) { return chunk ^ (2 * ((row >> 3) & 1)); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* p0, const bf16_t* p1) {
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p1));
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(NTHR) void gemm_tn2_kernel(const bf16_t* __restrict__ dC, int ldc, const bf16_t* __restrict__ X,
+                                                        int ldx, float* __restrict__ dW, int ldw, float* __restrict__ db, int M,
+                                                        int N, int K, int Nstore, int Kstore, int tilesK, int ntile, int nsplit,
+                                                        int rps) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem);           // [2][32][128]
+  bf16_t* sB = sA + 2 * TBM * TBN;                        // [2][32][160]
+  float* sC = reinterpret_cast<float*>(smem);
+  float* sRed = reinterpret_cast<float*>(smem);
+
+  // XCD-aware: the ntile workgroups of one split (same rows of dC / X) sit on one XCD back to back
+  const int b = blockIdx.x, xcd = b & 7, local = b >> 3;
+  const int split = (local / ntile) * 8 + xcd, tile = local % ntile;
+  if (split >= nsplit) return;
+  const int tn = tile / tilesK, tk = tile % tilesK;
+  const int n0 = tn * TBN, k0 = tk * TBK;
+  const int mbeg = split * rps, mend = min(M, mbeg + rps);
+  if (mbeg >= mend) return;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  const bool do_db = (db != nullptr) && (tk == 0);
+
+  uint4 ra[2], rb[3];
+  float colsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) colsum[e] = 0.f;
+
+  auto gload = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * NTHR, row = c >> 4, ch = c & 15;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (mt + row < mend && n0 + ch * 8 < N) z = *reinterpret_cast<const uint4*>(dC + (size_t)(mt + row) * ldc + n0 + ch * 8);
+      ra[i] = z;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = tid + i * NTHR, row = c / 20, ch = c - row * 20;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (c < TBM * 20 && mt + row < mend && k0 + ch * 8 < K) z = *reinterpret_cast<const uint4*>(X + (size_t)(mt + row) * ldx + k0 + ch * 8);
+      rb[i] = z;
+    }
+  };
+  auto swrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * NTHR, row = c >> 4, ch = c & 15;
+      *reinterpret_cast<uint4*>(sA + buf * TBM * TBN + row * TBN + swz_a(row, ch) * 8) = ra[i];
+      if (do_db) {
+        Chunk cc;
+        cc.u = ra[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) colsum[e] += (float)cc.h[e];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = tid + i * NTHR, row = c / 20, ch = c - row * 20;
+      if (c < TBM * 20) *reinterpret_cast<uint4*>(sB + buf * TBM * TBK + row * TBK + swz_b(row, ch) * 8) = rb[i];
+    }
+  };
+
+  f32x4 acc[4][5];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read lane geometry: 16-lane group g holds m rows 8g..8g+7; lane 4q+p of the group
+  // addresses row q, columns 4p..4p+3 of a 4 x 16 block
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int r0 = 8 * g + q, r1 = r0 + 4;
+
+  const int nk = (mend - mbeg + TBM - 1) / TBM;
+  gload(mbeg);
+  swrite(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload(mbeg + (kt + 1) * TBM);
+    {
+      const bf16_t* a = sA + cur * TBM * TBN;
+      const bf16_t* bq = sB + cur * TBM * TBK;
+      bf16x8 af[4], bf[5];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int chunk = (wm * 64 + i * 16) / 8 + (pp >> 1), off = 4 * (pp & 1);
+        af[i] = tr_frag(a + r0 * TBN + swz_a(r0, chunk) * 8 + off, a + r1 * TBN + swz_a(r1, chunk) * 8 + off);
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int chunk = (wn * 80 + j * 16) / 8 + (pp >> 1), off = 4 * (pp & 1);
+        bf[j] = tr_frag(bq + r0 * TBK + swz_b(r0, chunk) * 8 + off, bq + r1 * TBK + swz_b(r1, chunk) * 8 + off);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) swrite(cur ^ 1);
+    __syncthreads();
+  }
+
+  if (do_db) {
+    const int ch = tid & 15, t = tid >> 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sRed[t * 128 + ch * 8 + e] = colsum[e];
+    __syncthreads();
+    if (tid < 128 && n0 + tid < Nstore) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int t2 = 0; t2 < 16; ++t2) sacc += sRed[t2 * 128 + tid];
+      atomicAdd(db + n0 + tid, sacc);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int col = wn * 80 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sC[(i * 16 + (lane >> 4) * 4 + r) * SCW + col] = acc[i][j][r];
+      }
+    }
+    __syncthreads();
+    for (int u = tid; u < 64 * (TBK / 4); u += NTHR) {
+      const int row = u / (TBK / 4), c0 = (u % (TBK / 4)) * 4;
+      const int n = n0 + half * 64 + row, k = k0 + c0;
+      if (n < Nstore && k < Kstore) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * SCW + c0);
+        float* dst = dW + (size_t)n * ldw + k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + e < Kstore) atomicAdd(dst + e, v[e]);
+      }
+    }
+  }
+}
+
+int launch(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
+           int Kstore, hipStream_t stream) {
+  const int tilesN = (N + TBN - 1) / TBN, tilesK = (K + TBK - 1) / TBK, ntile = tilesN * tilesK;
+  int nsplit = (256 * 6 + ntile - 1) / ntile;
+  int rps = (M + nsplit - 1) / nsplit;
+  rps = ((rps + TBM - 1) / TBM) * TBM;
+  if (rps < 16 * TBM) rps = 16 * TBM;
+  nsplit = (M + rps - 1) / rps;
+  const int grid = ((nsplit + 7) / 8) * 8 * ntile;
+  NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM));
+  hipLaunchKernelGGL(gemm_tn2_kernel, dim3(grid), dim3(NTHR), SMEM, stream, (const bf16_t*)dC, ldc, (const bf16_t*)X, ldx, dW, ldw,
+                     db, M, N, K, Nstore, Kstore, tilesK, ntile, nsplit, rps);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+}  // namespace tn2
+
 // ---- host side ---------------------------------------------------------------------------
 template <typename K> int set_smem(K kernel, size_t bytes) {
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -571,6 +766,11 @@ int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float
   NR_CHECK_ARG(N % ch == 0 && K % ch == 0 && ldc % ch == 0 && A.ld % ch == 0, "gemm_tn: N=%d K=%d ldc=%d lda=%d must be multiples of %d",
                N, K, ldc, A.ld, ch);
   NR_CHECK_ARG(((uintptr_t)A.base & 15) == 0 && ((uintptr_t)dC & 15) == 0, "gemm_tn: operands must be 16-byte aligned");
+  static const bool tn_v1 = getenv("NR_TN_V1") != nullptr;
+  if (!tn_v1 && dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0) {
+    NrProfScope ps(stream, "gemm_tn2[bf16,M=%d,N=%d,K=%d]", M, N, K);
+    return tn2::launch(dC, ldc, A.base, A.ld, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+  }
   NrProfScope ps(stream, "gemm_tn[%s,rows=%d,M=%d,N=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", A.kind, M, N, K);
   return dtype == NR_BF16 ? launch_tn_d<bf16_t>(dC, ldc, A, dW, ldw, db, M, N, K, Nstore, Kstore, stream)
                           : launch_tn_d<float>(dC, ldc, A, dW, ldw, db, M, N, K, Nstore, Kstore, stream);

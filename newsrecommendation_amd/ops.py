@@ -123,18 +123,23 @@ class MHSAFunction(Function):
         dev = wq.device
         qkv = torch.empty(n * L, 3 * N, dtype=torch_dtype(code), device=dev)
         y = torch.empty(n, L, N, dtype=torch_dtype(code), device=dev)
+        # training with a gather source: keep the gathered + dropped-out rows for the weight-gradient GEMM
+        keep_rows = gather and any(ctx.needs_input_grad[1:7])
+        Kp = round_up(d_model, ch)
+        x_rows = torch.empty(n * L, Kp, dtype=torch_dtype(code), device=dev) if keep_rows else None
         d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=d_head, dtype=code,
                           src_kind=NR_SRC_GATHER if gather else NR_SRC_DENSE, x=ptr(src), ldx=ldx, ids=ptr(ids),
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
-                          mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p))
+                          mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
+                          x_rows=ptr(x_rows), ld_rows=Kp)
         check(_lib.lib().nr_mhsa_fwd(C.byref(d), ptr(qkv), ptr(y), _stream()), "nr_mhsa_fwd")
         ctx.cfg, ctx.dims = cfg, (n, L, N, d_model, heads, d_head, ldx, gather)
-        ctx.save_for_backward(src, ids, mask_c, w_p, b_p, wcat, qkv)
+        ctx.save_for_backward(src, ids, mask_c, w_p, b_p, wcat, qkv, x_rows)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        src, ids, mask_c, w_p, b_p, wcat, qkv = ctx.saved_tensors
+        src, ids, mask_c, w_p, b_p, wcat, qkv, x_rows = ctx.saved_tensors
         cfg = ctx.cfg
         n, L, N, d_model, heads, d_head, ldx, gather = ctx.dims
         code, dev = cfg["code"], dy.device
@@ -155,7 +160,8 @@ class MHSAFunction(Function):
         d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=d_head, dtype=code,
                           src_kind=NR_SRC_GATHER if gather else NR_SRC_DENSE, x=ptr(src), ldx=ldx, ids=ptr(ids),
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
-                          mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p))
+                          mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
+                          x_rows=ptr(x_rows), ld_rows=x_rows.shape[1] if x_rows is not None else 0)
         check(_lib.lib().nr_mhsa_bwd(C.byref(d), ptr(qkv), ptr(dy), ptr(dqkv), ptr(w_t), w_t.shape[1] if w_t is not None else 0,
                                      ptr(dw), ptr(db), ptr(dx), ptr(dtable), _stream()), "nr_mhsa_bwd")
         gx = dtable if gather else dx
