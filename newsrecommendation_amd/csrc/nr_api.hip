@@ -177,9 +177,10 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   if ((rc = mhsa_rows(d, &A))) return rc;
   EpiArgs ep = store_epi(qkv, 3 * N, d->dtype, d->b_qkv, 0);
   if (d->x_rows != nullptr && d->src_kind == NR_SRC_GATHER) {
+    // gather + dropout once into x_rows (kept for the backward), then a plain dense projection GEMM
     NR_CHECK_ARG(d->ld_rows >= Kp && d->ld_rows % nr_chunk(d->dtype) == 0, "mhsa_fwd: ld_rows=%d must cover %d", d->ld_rows, Kp);
-    ep.rows_out = d->x_rows;
-    ep.ld_rows_out = d->ld_rows;
+    if ((rc = nr_launch_rows_materialize(d->dtype, A, d->x_rows, d->ld_rows, M, Kp, s))) return rc;
+    A = dense_rows(d->x_rows, d->ld_rows, d->d_model);
   }
   if ((rc = nr_launch_gemm_nt(d->dtype, A, d->w_qkv, d->ldw, M, 3 * N, Kp, EPI_STORE, ep, s))) return rc;
   return nr_launch_attn(false, d->dtype, qkv, d->mask, y, nullptr, nullptr, d->n, d->L, d->heads, d->d_head,

@@ -46,5 +46,6 @@ struct EpiArgs {
 // C-level launchers (enqueue only).  dtype selects T.
 int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi,
                       const EpiArgs& ep, hipStream_t stream);
+int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, int M, int K, hipStream_t stream);
 int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db,
                       int M, int N, int K, int Nstore, int Kstore, hipStream_t stream);

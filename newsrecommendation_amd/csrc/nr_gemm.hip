@@ -137,6 +137,19 @@ __device__ __forceinline__ uint4 load_ctx_chunk(const RowSrc& s, const RowCtx<T>
   return ch.u;
 }
 
+// Materialise rows(A) (gather + dropout) as a dense [M, K] operand: every element is hashed once here
+// instead of once per 128-column tile inside the GEMM.
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void rows_materialize_kernel(RowSrc A, T* __restrict__ out, int ldo, int M, int K) {
+  constexpr int CH = 16 / (int)sizeof(T);
+  const int cpr = K / CH;
+  const size_t total = (size_t)M * cpr;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(t / cpr), k = (int)(t - (size_t)m * cpr) * CH;
+    *reinterpret_cast<uint4*>(out + (size_t)m * ldo + k) = load_rows_chunk<T, KIND>(A, m, k, M, K);
+  }
+}
+
 // ---- MFMA fragments --------------------------------------------------------------------
 struct F8 { float v[8]; };
 template <typename T> struct FragOf;
@@ -158,7 +171,9 @@ __device__ __forceinline__ void mma(f32x4& acc, const F8& a, const F8& b) {
   for (int e = 0; e < 8; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[e], b.v[e], acc, 0, 0, 0);
 }
 
-template <typename T>
+// SWAP = false: acc[i][j][r] = C[row i*16 + 4*(lane>>4) + r][col j*16 + (lane&15)]   (A rows on the MFMA row side)
+// SWAP = true : acc[i][j][r] = C[row i*16 + (lane&15)][col j*16 + 4*(lane>>4) + r]   (a lane owns 4 consecutive columns)
+template <typename T, bool SWAP>
 __device__ __forceinline__ void mma_tile_step(f32x4 (&acc)[4][4], const T* sA, const T* sB, int wm, int wn, int lane) {
   using TL = TileCfg<T>;
   typename FragOf<T>::type a[4], b[4];
@@ -170,7 +185,10 @@ __device__ __forceinline__ void mma_tile_step(f32x4 (&acc)[4][4], const T* sA, c
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) mma(acc[i][j], a[i], b[j]);
+    for (int j = 0; j < 4; ++j) {
+      if (SWAP) mma(acc[i][j], b[j], a[i]);
+      else mma(acc[i][j], a[i], b[j]);
+    }
 }
 
 // ---- epilogue emit: 4 consecutive columns of one row ------------------------------------
@@ -234,6 +252,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __rest
   if (tm >= tilesM) return;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  constexpr bool DIRECT = false;   // direct 8-byte stores (32-B row segments) measured slower than the LDS-staged epilogue
 
   uint4 ra[TL::NCH], rb[TL::NCH];
   RowCtx<T> rctx[TL::NCH];
@@ -274,9 +293,38 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __rest
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
-    mma_tile_step<T>(acc, sA + cur * BM * TL::SK, sB + cur * BN * TL::SK, wm, wn, lane);
+    mma_tile_step<T, DIRECT>(acc, sA + cur * BM * TL::SK, sB + cur * BN * TL::SK, wm, wn, lane);
     if (kt + 1 < nk) swrite(cur ^ 1, (kt + 1) * BK);
     __syncthreads();
+  }
+
+  if (DIRECT) {
+    // a lane owns 4 consecutive output columns of one row: bias / tanh / rank-1 term in registers, then one
+    // 8-byte (bf16) or 16-byte (f32) store per MFMA tile -- no LDS round trip.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+        if (n >= N) continue;
+        f32x4 v = acc[i][j];
+        if (EPI == EPI_STORE) {
+          if (ep.bias != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < N) v[r] += ep.bias[n + r];
+          }
+          if (ep.act_tanh) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+          }
+        }
+        emit4<EPI>(ep, m, n, N, v);
+      }
+    }
+    return;
   }
 
   // accumulators -> fp32 LDS tile, 64 rows at a time (bias / tanh applied here, column is lane-constant),
@@ -423,7 +471,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_kernel(const T* __restrict__ dC,
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload(mbeg + (kt + 1) * BK);
-    mma_tile_step<T>(acc, sA + cur * BM * TL::SK, sB + cur * BN * TL::SK, wm, wn, lane);
+    mma_tile_step<T, false>(acc, sA + cur * BM * TL::SK, sB + cur * BN * TL::SK, wm, wn, lane);
     if (kt + 1 < nk) swrite(cur ^ 1);
     __syncthreads();
   }
@@ -676,6 +724,148 @@ template <typename K> int set_smem(K kernel, size_t bytes) {
   return NR_OK;
 }
 
+
+// =========================================================================================
+// NT "wide" (bf16, dense A): one workgroup computes ALL N <= 16*NT16 output columns of a 128-row
+// M-tile, so the activation operand A [M, K] is streamed from HBM exactly once (the tiled kernel
+// re-reads it once per 128-column tile).  8 waves = 4 (M) x 2 (N halves); a wave owns 32 rows x
+// NT16/2 column tiles (2 x NT16/2 MFMA tiles, <= 104 accumulator registers -> 2 waves per SIMD);
+// the weight tile [N, 32] per k-step comes from L2.  Epilogue through a 32-row fp32 LDS tile
+// (row-contiguous 8/16-byte stores, 256-byte atomic segments).
+// Used for att_fc1 (N=200), the pooling backward dX (N=400) and the embedding-gradient GEMM (N=300).
+// =========================================================================================
+constexpr int WTHR = 512;
+
+template <int EPI, int NT16>
+__global__ __launch_bounds__(WTHR) void gemm_nt_wide_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
+                                                            int ldb, int M, int N, int K, EpiArgs ep) {
+  constexpr int SK = 40, WBN = NT16 * 16, HN = (NT16 + 1) / 2;   // HN: column tiles per wave
+  constexpr int NCB = (WBN * 4 + WTHR - 1) / WTHR;
+  constexpr int SCW = WBN + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem);   // [2][128][SK]
+  bf16_t* sB = sA + 2 * BM * SK;                  // [2][WBN][SK]
+  float* sC = reinterpret_cast<float*>(smem);     // epilogue: [32][SCW]
+  const int m0 = blockIdx.x * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+
+  uint4 ra, rb[NCB];
+  auto gload = [&](int k0) {
+    {
+      const int row = tid >> 2, kc = (tid & 3) * 8;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (m0 + row < M && k0 + kc < K) z = *reinterpret_cast<const uint4*>(A + (size_t)(m0 + row) * lda + k0 + kc);
+      ra = z;
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int c = tid + i * WTHR, row = c >> 2, kc = (c & 3) * 8;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (row < WBN && row < N && k0 + kc < K) z = *reinterpret_cast<const uint4*>(B + (size_t)row * ldb + k0 + kc);
+      rb[i] = z;
+    }
+  };
+  auto swrite = [&](int buf) {
+    {
+      const int row = tid >> 2, kc = (tid & 3) * 8;
+      *reinterpret_cast<uint4*>(sA + buf * BM * SK + row * SK + kc) = ra;
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      const int c = tid + i * WTHR, row = c >> 2, kc = (c & 3) * 8;
+      if (row < WBN) *reinterpret_cast<uint4*>(sB + buf * WBN * SK + row * SK + kc) = rb[i];
+    }
+  };
+
+  f32x4 acc[2][HN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < HN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fk = (lane >> 4) * 8;
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  swrite(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    {
+      const bf16_t* a = sA + cur * BM * SK;
+      const bf16_t* bq = sB + cur * WBN * SK;
+      bf16x8 af[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a + (wm * 32 + i * 16 + fr) * SK + fk);
+#pragma unroll
+      for (int j = 0; j < HN; ++j) {
+        const int jt = wn * HN + j;
+        if (jt < NT16) {
+          const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bq + (jt * 16 + fr) * SK + fk);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    if (kt + 1 < nk) swrite(cur ^ 1);
+    __syncthreads();
+  }
+  // epilogue: 32 rows (one wm group) at a time through the fp32 LDS tile
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    if (pass) __syncthreads();
+    if (wm == pass) {
+#pragma unroll
+      for (int j = 0; j < HN; ++j) {
+        const int jt = wn * HN + j;
+        if (jt < NT16) {
+          const int col = jt * 16 + (lane & 15);
+          float bv = 0.f;
+          if (EPI == EPI_STORE && ep.bias != nullptr && col < N) bv = ep.bias[col];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = acc[i][j][r] + bv;
+              if (EPI == EPI_STORE && ep.act_tanh) v = tanhf(v);
+              sC[(i * 16 + (lane >> 4) * 4 + r) * SCW + col] = v;
+            }
+        }
+      }
+    }
+    __syncthreads();
+    for (int u = tid; u < 32 * (WBN / 4); u += WTHR) {
+      const int row = u / (WBN / 4), c0 = (u % (WBN / 4)) * 4;
+      const int m = m0 + pass * 32 + row;
+      if (m < M && c0 < N) emit4<EPI>(ep, m, c0, N, *reinterpret_cast<const f32x4*>(sC + row * SCW + c0));
+    }
+  }
+}
+
+template <int EPI, int NT16>
+int launch_nt_wide_t(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
+  constexpr size_t stage = (size_t)2 * (BM + NT16 * 16) * 40 * sizeof(bf16_t);
+  constexpr size_t epi = (size_t)32 * (NT16 * 16 + 4) * sizeof(float);
+  constexpr size_t smem = stage > epi ? stage : epi;
+  auto kern = gemm_nt_wide_kernel<EPI, NT16>;
+  NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3((M + BM - 1) / BM), dim3(WTHR), smem, stream, (const bf16_t*)A.base, A.ld, (const bf16_t*)B, ldb, M,
+                     N, K, ep);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+template <int NT16>
+int launch_nt_wide_e(const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi, const EpiArgs& ep, hipStream_t s) {
+  switch (epi) {
+    case EPI_STORE: return launch_nt_wide_t<EPI_STORE, NT16>(A, B, ldb, M, N, K, ep, s);
+    case EPI_POOLBWD: return launch_nt_wide_t<EPI_POOLBWD, NT16>(A, B, ldb, M, N, K, ep, s);
+    case EPI_SCATTER: return launch_nt_wide_t<EPI_SCATTER, NT16>(A, B, ldb, M, N, K, ep, s);
+  }
+  nr_set_error("gemm_nt_wide: bad epilogue %d", epi);
+  return NR_ERR_ARG;
+}
+
 template <typename T, int KIND, int EPI>
 int launch_nt_t(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
   const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
@@ -747,6 +937,21 @@ int launch_tn_d(const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, fl
 
 }  // namespace
 
+int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, int M, int K, hipStream_t stream) {
+  const int ch = nr_chunk(dtype);
+  NR_CHECK_ARG(A.kind == ROWS_GATHER && K % ch == 0 && ldo % ch == 0 && ldo >= K, "rows_materialize: bad arguments");
+  NrProfScope ps(stream, "rows_materialize[%s,M=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", M, K);
+  const size_t total = (size_t)M * (K / ch);
+  size_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  if (dtype == NR_BF16)
+    hipLaunchKernelGGL((rows_materialize_kernel<bf16_t, ROWS_GATHER>), dim3((unsigned)grid), dim3(256), 0, stream, A, (bf16_t*)out, ldo, M, K);
+  else
+    hipLaunchKernelGGL((rows_materialize_kernel<float, ROWS_GATHER>), dim3((unsigned)grid), dim3(256), 0, stream, A, (float*)out, ldo, M, K);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
 int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi, const EpiArgs& ep,
                       hipStream_t stream) {
   const int ch = nr_chunk(dtype);
@@ -754,6 +959,13 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
   NR_CHECK_ARG(K % ch == 0 && ldb % ch == 0 && A.ld % ch == 0, "gemm_nt: K=%d ldb=%d lda=%d must be multiples of %d", K, ldb, A.ld, ch);
   NR_CHECK_ARG(((uintptr_t)A.base & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_nt: operands must be 16-byte aligned");
   if (epi != EPI_SCATTER) NR_CHECK_ARG(ep.ldc % 4 == 0 && ((uintptr_t)ep.C & 15) == 0, "gemm_nt: output ld %d / alignment", ep.ldc);
+  static const bool no_wide = getenv("NR_NT_NOWIDE") != nullptr;
+  if (!no_wide && dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0 && N <= 400 && ep.rows_out == nullptr) {
+    NrProfScope ps(stream, "gemm_nt_wide[bf16,epi=%d,M=%d,N=%d,K=%d]", epi, M, N, K);
+    if (N <= 208) return launch_nt_wide_e<13>(A, B, ldb, M, N, K, epi, ep, stream);
+    if (N <= 320) return launch_nt_wide_e<20>(A, B, ldb, M, N, K, epi, ep, stream);
+    return launch_nt_wide_e<25>(A, B, ldb, M, N, K, epi, ep, stream);
+  }
   NrProfScope ps(stream, "gemm_nt[%s,rows=%d,epi=%d,M=%d,N=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", A.kind, epi, M, N, K);
   return dtype == NR_BF16 ? launch_nt_d<bf16_t>(A, B, ldb, M, N, K, epi, ep, stream)
                           : launch_nt_d<float>(A, B, ldb, M, N, K, epi, ep, stream);
