@@ -211,6 +211,16 @@ int nr_score_eval(const float* news_vecs, int ld_news, const int32_t* cand_ids, 
 int nr_prof_enable(int on);
 int nr_prof_collect(char* buf, size_t n);
 
+/* ---------------------------------------------------------------------------------------
+ * The two MFMA GEMM building blocks on dense operands (used by every op above; exported for unit tests
+ * and kernel-level measurement).  A [M, lda], B [N, ldb] of dtype; C [M, ldc] of out_dtype:
+ *   nr_gemm_nt:  C = A . B^T (+ bias[N]) (tanh if act_tanh)
+ *   nr_gemm_tn:  dW[N, ldw] (fp32) += dC[M, ldc]^T . A[M, lda] ; db[N] += column sums of dC (db may be NULL) */
+int nr_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, const float* bias, int act_tanh, void* C,
+               int ldc, int out_dtype, int M, int N, int K, nr_stream_t stream);
+int nr_gemm_tn(int dtype, const void* dC, int ldc, const void* A, int lda, float* dW, int ldw, float* db, int M, int N,
+               int K, nr_stream_t stream);
+
 /* Test hook: materialise the dropout keep mask (1.0 / 0.0) for `count` element indices. */
 int nr_dropout_mask(float* out, uint32_t count, float p, uint32_t seed, nr_stream_t stream);
 

@@ -71,6 +71,8 @@ SIGNATURES = {
     "nr_score_ce_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "nr_score_ce_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "nr_score_eval": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
+    "nr_gemm_nt": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "nr_gemm_tn": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
     "nr_dropout_mask": [_vp, _u32, _f, _u32, _vp],
     "nr_prof_enable": [_i],
     "nr_prof_collect": [C.c_char_p, C.c_size_t],

@@ -165,6 +165,21 @@ int nr_last_error(char* buf, size_t n) {
   return (int)strlen(g_err);
 }
 
+int nr_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, const float* bias, int act_tanh, void* C, int ldc,
+               int out_dtype, int M, int N, int K, nr_stream_t stream) {
+  NR_CHECK_ARG(dtype_ok(dtype) && dtype_ok(out_dtype) && A && B && C, "gemm_nt: bad dtype / null operand");
+  RowSrc a = dense_rows(A, lda, K);
+  EpiArgs ep = store_epi(C, ldc, out_dtype, bias, act_tanh);
+  return nr_launch_gemm_nt(dtype, a, B, ldb, M, N, K, EPI_STORE, ep, (hipStream_t)stream);
+}
+
+int nr_gemm_tn(int dtype, const void* dC, int ldc, const void* A, int lda, float* dW, int ldw, float* db, int M, int N, int K,
+               nr_stream_t stream) {
+  NR_CHECK_ARG(dtype_ok(dtype) && dC && A && dW, "gemm_tn: bad dtype / null operand");
+  RowSrc a = dense_rows(A, lda, K);
+  return nr_launch_gemm_tn(dtype, dC, ldc, a, dW, ldw, db, M, N, K, N, K, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------- MHSA
 int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   int rc = mhsa_check(d);

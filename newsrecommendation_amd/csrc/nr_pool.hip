@@ -11,19 +11,57 @@ namespace {
 // One workgroup per sequence; a wave per token for the dot products, a thread per column for
 // the weighted sum (coalesced over the [L, N] tile).
 // ------------------------------------------------------------------------------------------
+// 16-byte chunk of T as floats
+template <typename T> struct ChunkOf { static constexpr int CH = 16 / (int)sizeof(T); };
+template <typename T> __device__ __forceinline__ void load_chunk_f(const T* p, float (&f)[ChunkOf<T>::CH]);
+template <> __device__ __forceinline__ void load_chunk_f<float>(const float* p, float (&f)[4]) {
+  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
+}
+template <> __device__ __forceinline__ void load_chunk_f<bf16_t>(const bf16_t* p, float (&f)[8]) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+}
+template <typename T> __device__ __forceinline__ void store_chunk_f(T* p, const float (&f)[ChunkOf<T>::CH]);
+template <> __device__ __forceinline__ void store_chunk_f<float>(float* p, const float (&f)[4]) {
+  *reinterpret_cast<f32x4*>(p) = (f32x4){f[0], f[1], f[2], f[3]};
+}
+template <> __device__ __forceinline__ void store_chunk_f<bf16_t>(bf16_t* p, const float (&f)[8]) {
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)f[e];
+  *reinterpret_cast<bf16x8*>(p) = v;
+}
+
+// <row (nchunks chunks of T), vec (fp32)> with one 16-byte load per lane, summed over the wave
+template <typename T>
+__device__ __forceinline__ float wave_row_dot(const T* __restrict__ row, const float* __restrict__ vec, int nchunks, int lane) {
+  constexpr int CH = ChunkOf<T>::CH;
+  float p = 0.f;
+  for (int c = lane; c < nchunks; c += 64) {
+    float f[CH];
+    load_chunk_f<T>(row + c * CH, f);
+#pragma unroll
+    for (int e = 0; e < CH; ++e) p = fmaf(f[e], vec[c * CH + e], p);
+  }
+  return wave_sum(p);
+}
+
+constexpr int POOL_RED_FLOATS = 256 * 8;   // LDS reduction scratch: [row groups][columns] <= 256 chunks of <= 8
+
 template <typename T>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, const T* __restrict__ e,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        const float* __restrict__ mask, float* __restrict__ alpha,
                                                        float* __restrict__ out, int ld_out, int L, int N, int q) {
+  constexpr int CH = ChunkOf<T>::CH;
   __shared__ float sS[64];
+  __shared__ float sRed[POOL_RED_FLOATS];
   const int seq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const size_t row0 = (size_t)seq * L;
   for (int l = wid; l < L; l += 4) {
-    const T* er = e + (row0 + l) * q;
-    float p = 0.f;
-    for (int c = lane; c < q; c += 64) p = fmaf((float)er[c], w2[c], p);
-    p = wave_sum(p);
+    const float p = wave_row_dot<T>(e + (row0 + l) * q, w2, q / CH, lane);
     if (lane == 0) sS[l] = p + b2[0];
   }
   __syncthreads();
@@ -40,10 +78,36 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, 
     }
   }
   __syncthreads();
-  for (int c = tid; c < N; c += 256) {
-    float acc = 0.f;
-    for (int l = 0; l < L; ++l) acc = fmaf(sS[l], (float)x[(row0 + l) * N + c], acc);
-    out[(size_t)seq * ld_out + c] = acc;
+  // out[c] = sum_l a_l x[l][c]: thread = (column chunk, row group); row groups reduced through LDS
+  const int nc = N / CH;
+  if (nc <= 256) {
+    const int nrg = 256 / nc, cx = tid % nc, rg = tid / nc;
+    if (rg < nrg) {
+      float acc[CH];
+#pragma unroll
+      for (int k = 0; k < CH; ++k) acc[k] = 0.f;
+      for (int l = rg; l < L; l += nrg) {
+        float f[CH];
+        load_chunk_f<T>(x + (row0 + l) * N + cx * CH, f);
+        const float a = sS[l];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) acc[k] = fmaf(a, f[k], acc[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k) sRed[rg * N + cx * CH + k] = acc[k];
+    }
+    __syncthreads();
+    for (int c = tid; c < N; c += 256) {
+      float v = 0.f;
+      for (int r = 0; r < nrg; ++r) v += sRed[r * N + c];
+      out[(size_t)seq * ld_out + c] = v;
+    }
+  } else {
+    for (int c = tid; c < N; c += 256) {
+      float acc = 0.f;
+      for (int l = 0; l < L; ++l) acc = fmaf(sS[l], (float)x[(row0 + l) * N + c], acc);
+      out[(size_t)seq * ld_out + c] = acc;
+    }
   }
 }
 
@@ -52,8 +116,9 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, 
 //   dA_l = <g, x_l> ; ds_l = a_l (dA_l - sum_u a_u dA_u) ; dpre_l = ds_l w2 (1 - e_l^2)
 //   dw2 += sum_l ds_l e_l ; db2 += sum_l ds_l
 // The direct term a_l g of dx and dpre.W1 are produced together by the GEMM epilogue
-// (EPI_POOLBWD).  Each workgroup handles SEQ_PER_BLOCK sequences and writes one partial row
-// of (dw2 | db2); nr_colsum_kernel reduces the partial rows deterministically.
+// (EPI_POOLBWD).  Each workgroup handles POOL_SPB sequences and writes one partial row
+// of (dw2 | db2); colsum_kernel reduces the partial rows deterministically.
+// All tile accesses are 16-byte chunks.
 // ------------------------------------------------------------------------------------------
 constexpr int POOL_SPB = 8;
 
@@ -62,21 +127,25 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ w2, const float* __restrict__ alpha,
                                                        const float* __restrict__ g, int ld_g, T* __restrict__ dpre,
                                                        float* __restrict__ partial, int n, int L, int N, int q) {
+  constexpr int CH = ChunkOf<T>::CH;
   __shared__ float sDA[64];
   __shared__ float sDS[64];
+  __shared__ float sRed[POOL_RED_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  float accw[4] = {0.f, 0.f, 0.f, 0.f};  // dw2 columns tid, tid+256, ...
+  const int qc = q / CH;                       // chunks per e row (<= 256: q <= 1024)
+  const int nrg = 256 / qc, cx = tid % qc, rg = tid / qc;
+  float accw[4] = {0.f, 0.f, 0.f, 0.f};        // dw2 columns tid, tid+256, ...
   float accb = 0.f;
+  float w2c[CH];
+#pragma unroll
+  for (int k = 0; k < CH; ++k) w2c[k] = w2[cx * CH + k];
   for (int s = 0; s < POOL_SPB; ++s) {
     const int seq = blockIdx.x * POOL_SPB + s;
     if (seq >= n) break;
     const size_t row0 = (size_t)seq * L;
     const float* gr = g + (size_t)seq * ld_g;
     for (int l = wid; l < L; l += 4) {
-      const T* xr = x + (row0 + l) * N;
-      float p = 0.f;
-      for (int c = lane; c < N; c += 64) p = fmaf(gr[c], (float)xr[c], p);
-      p = wave_sum(p);
+      const float p = wave_row_dot<T>(x + (row0 + l) * N, gr, N / CH, lane);
       if (lane == 0) sDA[l] = p;
     }
     __syncthreads();
@@ -87,17 +156,31 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
       if (lane < L) sDS[lane] = a * (dA - rd);
     }
     __syncthreads();
-    for (int idx = tid; idx < L * q; idx += 256) {
-      const int l = idx / q, c = idx - l * q;
-      const float ev = (float)e[(row0 + l) * q + c];
-      dpre[(row0 + l) * q + c] = (T)(sDS[l] * w2[c] * (1.f - ev * ev));
+    float wacc[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) wacc[k] = 0.f;
+    if (rg < nrg) {
+      for (int l = rg; l < L; l += nrg) {
+        float f[CH], o[CH];
+        load_chunk_f<T>(e + (row0 + l) * q + cx * CH, f);
+        const float ds = sDS[l];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          o[k] = ds * w2c[k] * (1.f - f[k] * f[k]);
+          wacc[k] = fmaf(ds, f[k], wacc[k]);
+        }
+        store_chunk_f<T>(dpre + (row0 + l) * q + cx * CH, o);
+      }
+#pragma unroll
+      for (int k = 0; k < CH; ++k) sRed[rg * q + cx * CH + k] = wacc[k];
     }
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = tid + k * 256;
       if (c < q) {
         float t = 0.f;
-        for (int l = 0; l < L; ++l) t = fmaf(sDS[l], (float)e[(row0 + l) * q + c], t);
+        for (int r = 0; r < nrg; ++r) t += sRed[r * q + c];
         accw[k] += t;
       }
     }
@@ -365,6 +448,7 @@ inline int grid_for(size_t total, int block = 256, int cap = 256 * 16) {
 int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
                             float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s) {
   NR_CHECK_ARG(L >= 1 && L <= 64, "additive_pool: L=%d must be in [1, 64]", L);
+  NR_CHECK_ARG((((uintptr_t)x | (uintptr_t)e) & 15) == 0 && q <= 1024, "additive_pool: x / e must be 16-byte aligned, q <= 1024");
   NrProfScope ps(s, "pool_core_fwd[n=%d,L=%d,N=%d,q=%d]", n, L, N, q);
   if (dtype == NR_BF16)
     hipLaunchKernelGGL(pool_fwd_kernel<bf16_t>, dim3(n), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)e, w2, b2, mask, alpha, out, ld_out, L, N, q);
@@ -381,6 +465,8 @@ int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float
                             hipStream_t s) {
   NR_CHECK_ARG(L >= 1 && L <= 64, "additive_pool: L=%d must be in [1, 64]", L);
   NR_CHECK_ARG(q <= 1024, "additive_pool: q=%d must be <= 1024", q);
+  NR_CHECK_ARG((((uintptr_t)x | (uintptr_t)e | (uintptr_t)dpre | (uintptr_t)g) & 15) == 0 && ld_g % 4 == 0,
+               "additive_pool_bwd: x / e / dpre / g must be 16-byte aligned");
   const int nb = nr_pool_partial_rows(n);
   NrProfScope ps(s, "pool_core_bwd[n=%d,L=%d,N=%d,q=%d]", n, L, N, q);
   if (dtype == NR_BF16)

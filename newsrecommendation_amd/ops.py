@@ -437,3 +437,29 @@ def dropout_mask(count: int, p: float, seed: int, device) -> torch.Tensor:
     out = torch.empty(count, dtype=torch.float32, device=device)
     check(_lib.lib().nr_dropout_mask(ptr(out), count, float(p), int(seed), _stream()), "nr_dropout_mask")
     return out
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, act_tanh=False, out_dtype=None) -> torch.Tensor:
+    """C = a . b^T (+bias)(tanh): the MFMA GEMM building block on dense operands (unit tests / measurement)."""
+    _need_gpu(a, b)
+    code = NR_BF16 if a.dtype == torch.bfloat16 else NR_F32
+    M, K = a.shape
+    N = b.shape[0]
+    out_dtype = out_dtype or a.dtype
+    c = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    check(_lib.lib().nr_gemm_nt(code, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(bias), int(act_tanh), ptr(c), N,
+                                NR_BF16 if out_dtype == torch.bfloat16 else NR_F32, M, N, K, _stream()), "nr_gemm_nt")
+    return c
+
+
+def gemm_tn(dc: torch.Tensor, a: torch.Tensor, with_bias_grad=True):
+    """dW = dc^T . a (fp32), db = column sums of dc: the weight-gradient GEMM building block."""
+    _need_gpu(dc, a)
+    code = NR_BF16 if a.dtype == torch.bfloat16 else NR_F32
+    M, N = dc.shape
+    K = a.shape[1]
+    dw = torch.zeros(N, K, dtype=torch.float32, device=a.device)
+    db = torch.zeros(N, dtype=torch.float32, device=a.device) if with_bias_grad else None
+    check(_lib.lib().nr_gemm_tn(code, ptr(dc), dc.stride(0), ptr(a), a.stride(0), ptr(dw), K, ptr(db), M, N, K, _stream()),
+          "nr_gemm_tn")
+    return dw, db
