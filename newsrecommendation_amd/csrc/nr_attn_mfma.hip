@@ -14,6 +14,8 @@
 //   S   = Q K^T, dP   = G V^T (lane = key j)    -> dK = dS^T Q, dV = P^T G
 // Softmax is the reference's (src/model/model_utils.py:47-53): exp, key mask after exp, denominator
 // sum + 1e-8, evaluated in the stable form with the row max factored out.
+#include <stdlib.h>
+
 #include "nr_common.h"
 
 namespace {
@@ -413,6 +415,275 @@ __global__ __launch_bounds__(AW * 64) void attn_mfma_bwd_kernel(AttnMArgs a) {
   }
 }
 
+
+// ==========================================================================================
+// bf16 fast path (d % 4 == 0, aligned slices): every operand lives in ONE row-major 32 x 32 LDS
+// image per matrix (64-byte rows, no padding, 16-byte chunk index XOR-swizzled by (row >> 2) & 3 so
+// that both the ds_read_b128 row fragments and the transposed reads are bank-conflict free).
+// Products that contract over tokens fetch their B operand with ds_read_b64_tr_b16 (a 4-token x
+// 16-column block delivered column-major) straight from the row-major image, and the outputs go
+// back to global memory through a transposed image written 8 bytes at a time and read with the
+// same instruction -- no element-wise transposing LDS traffic at all.
+// ==========================================================================================
+namespace b16 {
+constexpr int IMG = 32 * 32;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ int ioff(int row, int col) { return row * 32 + ((((col >> 3) ^ ((row >> 2) & 3)) << 3) | (col & 7)); }
+__device__ __forceinline__ bf16x4 trd(const bf16_t* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p)); }
+
+template <bool DROP>
+__device__ __forceinline__ void stage(const bf16_t* __restrict__ src, size_t ld, int L, int d, bf16_t* img, int lane,
+                                      const DropCfg& drop, uint32_t eidx0, uint32_t erow) {
+  const int r = lane & 31, part = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * (2 * q + part);
+    bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (r < L && c < d) {
+      v = *reinterpret_cast<const bf16x4*>(src + (size_t)r * ld + c);
+      if (DROP && drop.thresh) {
+        const uint32_t e0 = eidx0 + (uint32_t)r * erow + (uint32_t)c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = nr_keep(drop.key, e0 + e, drop.thresh) ? (bf16_t)((float)v[e] * drop.scale) : (bf16_t)0.f;
+      }
+    }
+    *reinterpret_cast<bf16x4*>(img + ioff(r, c)) = v;
+  }
+}
+
+// acc[row a][col b] += sum_c A[a][c] B[b][c]
+__device__ __forceinline__ void mm_rr(f32x16& acc, const bf16_t* A, const bf16_t* B, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + ioff(r, 16 * s + 8 * h));
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + ioff(r, 16 * s + 8 * h));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+}
+
+// acc[row i][col c] += sum_j X[j][i] Bm[j][c]; X = accumulator tile, Bm = ROW-MAJOR image [token j][c]
+__device__ __forceinline__ void mm_xt(f32x16& acc, const f32x16& x, const bf16_t* Bm, int lane) {
+  const int g16 = lane >> 4, h = g16 >> 1, cb = 16 * (g16 & 1), qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = (bf16_t)x[8 * s + e];
+    const bf16x4 lo = trd(Bm + ioff(16 * s + 4 * h + qq, cb + 4 * pp));
+    const bf16x4 hi = trd(Bm + ioff(16 * s + 8 + 4 * h + qq, cb + 4 * pp));
+    const bf16x8 b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+}
+
+// accumulator tile (col c on the lane, rows in registers) -> TRANSPOSED image Ot[c][row], 8 bytes per write
+__device__ __forceinline__ void acc_to_img_t(const f32x16& acc, float mul, bf16_t* Ot, int lane) {
+  const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bf16x4 v = {(bf16_t)(acc[4 * k] * mul), (bf16_t)(acc[4 * k + 1] * mul), (bf16_t)(acc[4 * k + 2] * mul),
+                      (bf16_t)(acc[4 * k + 3] * mul)};
+    *reinterpret_cast<bf16x4*>(Ot + ioff(c, 8 * k + 4 * h)) = v;
+  }
+}
+
+// transposed image Ot[c][row] -> global rows, 4 columns (8 bytes) per lane and store
+template <bool DROP>
+__device__ __forceinline__ void img_t_to_global(const bf16_t* Ot, bf16_t* __restrict__ dst, size_t ld, int L, int d, int lane,
+                                                const DropCfg& drop, uint32_t eidx0, uint32_t erow) {
+  const int g16 = lane >> 4, part = g16 >> 1, rb = 16 * (g16 & 1), qq = (lane & 15) >> 2, pp = lane & 3, r = lane & 31;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * (2 * q + part);
+    bf16x4 v = trd(Ot + ioff(c + qq, rb + 4 * pp));   // executed by every lane (EXEC must be full)
+    if (r < L && c < d) {
+      if (DROP && drop.thresh) {
+        const uint32_t e0 = eidx0 + (uint32_t)r * erow + (uint32_t)c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = nr_keep(drop.key, e0 + e, drop.thresh) ? (bf16_t)((float)v[e] * drop.scale) : (bf16_t)0.f;
+      }
+      *reinterpret_cast<bf16x4*>(dst + (size_t)r * ld + c) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  bf16_t* base = reinterpret_cast<bf16_t*>(smem) + (size_t)wid * 3 * IMG;
+  bf16_t *sQ = base, *sK = base + IMG, *sV = base + 2 * IMG;
+  float* sMask = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + (size_t)AW * 3 * IMG) + wid * 32;
+  const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
+  bf16_t* y = reinterpret_cast<bf16_t*>(a.y);
+  const int N = a.N, L = a.L, d = a.d;
+  const long total = (long)a.n * a.heads;
+  const int h2 = lane >> 5;
+  DropCfg nodrop;
+  nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
+
+  for (long p0 = (long)blockIdx.x * AW; p0 < total; p0 += (long)gridDim.x * AW) {
+    const long p = p0 + wid;
+    const bool active = p < total;
+    const int seq = active ? (int)(p / a.heads) : 0, head = active ? (int)(p % a.heads) : 0;
+    const size_t row0 = (size_t)seq * L;
+    const bf16_t* src = qkv + row0 * 3 * N + head * d;
+    const int Ls = active ? L : 0;                       // inactive waves stage zeros and store nothing
+    stage<false>(src, 3 * N, Ls, d, sQ, lane, nodrop, 0, 0);
+    stage<false>(src + N, 3 * N, Ls, d, sK, lane, nodrop, 0, 0);
+    stage<false>(src + 2 * N, 3 * N, Ls, d, sV, lane, nodrop, 0, 0);
+    if (lane < 32) sMask[lane] = (lane < Ls) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
+    __syncthreads();
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    mm_rr(st, sK, sQ, lane);  // S^T[j][i]
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] *= a.scale;
+      if (rowof(r, h2) < L) m = fmaxf(m, st[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = rowof(r, h2);
+      const float e = (j < L) ? __expf(st[r] - m) * sMask[j] : 0.f;
+      st[r] = e;
+      sum += e;
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / (sum + 1e-8f * __expf(-m));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] *= inv;
+    f32x16 ctx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+    mm_xt(ctx, st, sV, lane);  // ctx[i][c]
+    __syncthreads();
+    acc_to_img_t(ctx, 1.f, sQ, lane);
+    __syncthreads();
+    img_t_to_global<true>(sQ, y + row0 * N + head * d, N, Ls, d, lane, a.drop, (uint32_t)(row0 * N + head * d), (uint32_t)N);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(AW * 64) void bwd_kernel(AttnMArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  bf16_t* base = reinterpret_cast<bf16_t*>(smem) + (size_t)wid * 4 * IMG;
+  bf16_t *sQ = base, *sK = base + IMG, *sV = base + 2 * IMG, *sG = base + 3 * IMG;
+  float* sF = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + (size_t)AW * 4 * IMG) + wid * 128;
+  float *sMask = sF, *sM = sF + 32, *sInv = sF + 64, *sRd = sF + 96;
+  const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
+  const bf16_t* dy = reinterpret_cast<const bf16_t*>(a.dy);
+  bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.dqkv);
+  const int N = a.N, L = a.L, d = a.d;
+  const long total = (long)a.n * a.heads;
+  const int h2 = lane >> 5, li = lane & 31;
+  DropCfg nodrop;
+  nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
+
+  for (long p0 = (long)blockIdx.x * AW; p0 < total; p0 += (long)gridDim.x * AW) {
+    const long p = p0 + wid;
+    const bool active = p < total;
+    const int seq = active ? (int)(p / a.heads) : 0, head = active ? (int)(p % a.heads) : 0;
+    const size_t row0 = (size_t)seq * L;
+    const int Ls = active ? L : 0;
+    const bf16_t* src = qkv + row0 * 3 * N + head * d;
+    stage<false>(src, 3 * N, Ls, d, sQ, lane, nodrop, 0, 0);
+    stage<false>(src + N, 3 * N, Ls, d, sK, lane, nodrop, 0, 0);
+    stage<false>(src + 2 * N, 3 * N, Ls, d, sV, lane, nodrop, 0, 0);
+    stage<true>(dy + row0 * N + head * d, N, Ls, d, sG, lane, a.drop, (uint32_t)(row0 * N + head * d), (uint32_t)N);
+    if (lane < 32) sMask[lane] = (lane < Ls) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
+    __syncthreads();
+    f32x16 dst;  // dS^T (lane = query i)
+    {
+      f32x16 st, dpt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+      mm_rr(st, sK, sQ, lane);   // S^T[j][i]
+      mm_rr(dpt, sV, sG, lane);  // dP^T[j][i]
+      float m = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        st[r] *= a.scale;
+        if (rowof(r, h2) < L) m = fmaxf(m, st[r]);
+      }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float sum = 0.f, rdu = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = rowof(r, h2);
+        const float e = (j < L) ? __expf(st[r] - m) * sMask[j] : 0.f;
+        st[r] = e;
+        sum += e;
+        rdu = fmaf(e, dpt[r], rdu);
+      }
+      sum += __shfl_xor(sum, 32, 64);
+      rdu += __shfl_xor(rdu, 32, 64);
+      const float inv = 1.f / (sum + 1e-8f * __expf(-m));
+      const float rd = rdu * inv;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[r] = st[r] * inv * (dpt[r] - rd);
+      if (lane < 32) {
+        sM[lane] = m;
+        sInv[lane] = inv;
+        sRd[lane] = rd;
+      }
+    }
+    __syncthreads();
+    f32x16 dq, dk, dv;
+    {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+      mm_xt(dq, dst, sK, lane);   // dQ[i][c] = sum_j dS[i][j] K[j][c]
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      mm_rr(s, sQ, sK, lane);     // S[i][j]
+      mm_rr(dp, sG, sV, lane);    // dP[i][j]
+      const float mj = sMask[li];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = rowof(r, h2);
+        const float pij = __expf(s[r] * a.scale - sM[i]) * mj * sInv[i];
+        s[r] = pij;
+        dp[r] = pij * (dp[r] - sRd[i]);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+      mm_xt(dk, dp, sQ, lane);    // dK[j][c] = sum_i dS[i][j] Q[i][c]
+      mm_xt(dv, s, sG, lane);     // dV[j][c] = sum_i P[i][j] G[i][c]
+    }
+    __syncthreads();
+    acc_to_img_t(dq, a.scale, sQ, lane);
+    acc_to_img_t(dk, a.scale, sK, lane);
+    acc_to_img_t(dv, 1.f, sV, lane);
+    __syncthreads();
+    bf16_t* op = dqkv + row0 * 3 * N + head * d;
+    img_t_to_global<false>(sQ, op, 3 * N, Ls, d, lane, nodrop, 0, 0);
+    img_t_to_global<false>(sK, op + N, 3 * N, Ls, d, lane, nodrop, 0, 0);
+    img_t_to_global<false>(sV, op + 2 * N, 3 * N, Ls, d, lane, nodrop, 0, 0);
+    __syncthreads();
+  }
+}
+
+int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
+  const long total = (long)a.n * a.heads;
+  long blocks = (total + AW - 1) / AW;
+  const size_t smem = bwd ? AW * (4 * IMG * sizeof(bf16_t) + 128 * sizeof(float)) : AW * (3 * IMG * sizeof(bf16_t) + 32 * sizeof(float));
+  const long cap = 256L * 4 * 4;
+  if (blocks > cap) blocks = cap;
+  if (bwd) hipLaunchKernelGGL(bwd_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
+  else hipLaunchKernelGGL(fwd_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+}  // namespace b16
+
 template <typename T>
 int launch_t(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   const long total = (long)a.n * a.heads;
@@ -449,5 +720,7 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   const uintptr_t al = dtype == NR_BF16 ? 7 : 15;
   a.vec = (d_head % 4 == 0) && (((uintptr_t)qkv | (uintptr_t)y | (uintptr_t)dy | (uintptr_t)dqkv) & al) == 0;
   NrProfScope ps(stream, "attn_mfma_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? "bwd" : "fwd", dtype == NR_BF16 ? "bf16" : "f32", n, L, heads, d_head);
+  static const bool old_path = getenv("NR_ATTN_OLD") != nullptr;
+  if (dtype == NR_BF16 && a.vec && !old_path) return b16::launch(bwd, a, stream);
   return dtype == NR_BF16 ? launch_t<bf16_t>(bwd, a, stream) : launch_t<float>(bwd, a, stream);
 }
