@@ -24,6 +24,7 @@ enum {
   EPI_STORE = 0,    // C = acc (+ bias[n]) (tanh)
   EPI_POOLBWD = 1,  // C = acc + rowscale[m] * G[(m / L) * ldg + n]
   EPI_SCATTER = 2,  // dtable[ids[m]*ldc + n] += keep(m*Dtrue+n) ? acc*scale : 0   (ids[m] != 0, n < Dtrue)
+  EPI_STORE_TANH = 3,  // C = tanh(acc + bias[n]) -- its own instantiation: tanhf costs ~50 VGPRs in the epilogue
 };
 
 struct EpiArgs {

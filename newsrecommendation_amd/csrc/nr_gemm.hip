@@ -252,7 +252,9 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __rest
   if (tm >= tilesM) return;
   const int m0 = tm * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
-  constexpr bool DIRECT = false;   // direct 8-byte stores (32-B row segments) measured slower than the LDS-staged epilogue
+  // bf16 outputs: operand roles are swapped so that a lane owns 4 consecutive output columns; the tile goes
+  // through a bf16 LDS image (one 8-byte write per MFMA tile) and leaves as 16-byte row-contiguous stores.
+  constexpr bool DIRECT = (sizeof(T) == 2) && (EPI != EPI_SCATTER);
 
   uint4 ra[TL::NCH], rb[TL::NCH];
   RowCtx<T> rctx[TL::NCH];
@@ -299,29 +301,61 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __rest
   }
 
   if (DIRECT) {
-    // a lane owns 4 consecutive output columns of one row: bias / tanh / rank-1 term in registers, then one
-    // 8-byte (bf16) or 16-byte (f32) store per MFMA tile -- no LDS round trip.
+    bf16_t* sCb = reinterpret_cast<bf16_t*>(smem);
+    constexpr int SCB = BN + 8;   // 272-byte rows
+    const bool out_bf16 = ep.out_dtype == NR_BF16;
+    // column tile outermost: the lane's 4 bias values are live for one tile column only (register pressure)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-      if (m >= M) continue;
+    for (int j = 0; j < 4; ++j) {
+      const int nl = wn * 64 + j * 16 + 4 * (lane >> 4), n = n0 + nl;
+      f32x4 bvec = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if ((EPI == EPI_STORE || EPI == EPI_STORE_TANH) && ep.bias != nullptr) {
+        if (n + 4 <= N) bvec = *reinterpret_cast<const f32x4*>(ep.bias + n);
+        else
+          for (int r = 0; r < 4; ++r)
+            if (n + r < N) bvec[r] = ep.bias[n + r];
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + 4 * (lane >> 4);
-        if (n >= N) continue;
-        f32x4 v = acc[i][j];
-        if (EPI == EPI_STORE) {
-          if (ep.bias != nullptr) {
+      for (int i = 0; i < 4; ++i) {
+        const int ml = wm * 64 + i * 16 + (lane & 15), m = m0 + ml;
+        f32x4 v = acc[i][j] + bvec;
+        if (EPI == EPI_STORE_TANH) {
 #pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+        }
+        if (EPI == EPI_POOLBWD && m < M && n < N) {
+          const float rs = ep.rowscale[m];
+          const float* grow = ep.G + (size_t)(m / ep.L) * ep.ldg;
+          if (n + 4 <= N && (ep.ldg & 3) == 0) {
+            v += rs * *reinterpret_cast<const f32x4*>(grow + n);
+          } else {
             for (int r = 0; r < 4; ++r)
-              if (n + r < N) v[r] += ep.bias[n + r];
-          }
-          if (ep.act_tanh) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+              if (n + r < N) v[r] += rs * grow[n + r];
           }
         }
-        emit4<EPI>(ep, m, n, N, v);
+        if (out_bf16) {
+          const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          *reinterpret_cast<bf16x4*>(sCb + ml * SCB + nl) = o;
+        } else if (m < M && n < N) {          // fp32 output from bf16 operands: direct 16-byte stores
+          float* dst = (float*)ep.C + (size_t)m * ep.ldc + n;
+          if (n + 4 <= N) *reinterpret_cast<f32x4*>(dst) = v;
+          else
+            for (int r = 0; r < 4 && n + r < N; ++r) dst[r] = v[r];
+        }
+      }
+    }
+    if (!out_bf16) return;
+    __syncthreads();
+    for (int u = tid; u < BM * (BN / 8); u += NTHR) {
+      const int row = u / (BN / 8), c0 = (u % (BN / 8)) * 8;
+      const int m = m0 + row, n = n0 + c0;
+      if (m < M && n < N) {
+        bf16_t* dst = (bf16_t*)ep.C + (size_t)m * ep.ldc + n;
+        if (n + 8 <= N && (ep.ldc % 8) == 0) {
+          *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(sCb + row * SCB + c0);
+        } else {
+          for (int e = 0; e < 8 && n + e < N; ++e) dst[e] = sCb[row * SCB + c0 + e];
+        }
       }
     }
     return;
@@ -333,7 +367,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __rest
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int col = wn * 64 + j * 16 + (lane & 15);
-    bv[j] = (EPI == EPI_STORE && ep.bias != nullptr && n0 + col < N) ? ep.bias[n0 + col] : 0.f;
+    bv[j] = ((EPI == EPI_STORE || EPI == EPI_STORE_TANH) && ep.bias != nullptr && n0 + col < N) ? ep.bias[n0 + col] : 0.f;
   }
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -347,7 +381,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __rest
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = acc[i][j][r] + bv[j];
-            if (EPI == EPI_STORE && ep.act_tanh) v = tanhf(v);
+            if (EPI == EPI_STORE_TANH) v = tanhf(v);
             sC[(i * 16 + (lane >> 4) * 4 + r) * SC + col] = v;
           }
       }
@@ -821,13 +855,13 @@ __global__ __launch_bounds__(WTHR) void gemm_nt_wide_kernel(const bf16_t* __rest
         if (jt < NT16) {
           const int col = jt * 16 + (lane & 15);
           float bv = 0.f;
-          if (EPI == EPI_STORE && ep.bias != nullptr && col < N) bv = ep.bias[col];
+          if ((EPI == EPI_STORE || EPI == EPI_STORE_TANH) && ep.bias != nullptr && col < N) bv = ep.bias[col];
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float v = acc[i][j][r] + bv;
-              if (EPI == EPI_STORE && ep.act_tanh) v = tanhf(v);
+              if (EPI == EPI_STORE_TANH) v = tanhf(v);
               sC[(i * 16 + (lane >> 4) * 4 + r) * SCW + col] = v;
             }
         }
@@ -859,10 +893,195 @@ template <int NT16>
 int launch_nt_wide_e(const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi, const EpiArgs& ep, hipStream_t s) {
   switch (epi) {
     case EPI_STORE: return launch_nt_wide_t<EPI_STORE, NT16>(A, B, ldb, M, N, K, ep, s);
+    case EPI_STORE_TANH: return launch_nt_wide_t<EPI_STORE_TANH, NT16>(A, B, ldb, M, N, K, ep, s);
     case EPI_POOLBWD: return launch_nt_wide_t<EPI_POOLBWD, NT16>(A, B, ldb, M, N, K, ep, s);
     case EPI_SCATTER: return launch_nt_wide_t<EPI_SCATTER, NT16>(A, B, ldb, M, N, K, ep, s);
   }
   nr_set_error("gemm_nt_wide: bad epilogue %d", epi);
+  return NR_ERR_ARG;
+}
+
+
+// =========================================================================================
+// NT "wide" with an LDS-DMA ring (bf16, dense A; B zero-padded to a multiple of 32 in K).
+// Same tile shape as gemm_nt_wide_kernel, but the operands are moved HBM/L2 -> LDS by
+// global_load_lds_dwordx4 (no staging registers, no ds_write) into a ring of NS stages with
+// NS-1 stages in flight (counted s_waitcnt vmcnt, one raw s_barrier per k-step), so the HBM
+// latency of the activation stream is covered by three k-steps of MFMA work.
+//   stage = [A tile 128 x 32][B tile WBN x 32][scratch]  : unpadded 64-byte rows
+//   a DMA wave-instruction fills 1 KB = 16 rows; the 16-byte chunk a lane FETCHES is XOR-permuted
+//   (chunk ^ P[(row >> 2) & 3], P = {0,2,3,1}) so that the later ds_read_b128 fragment reads of the
+//   linear LDS image are bank-conflict free (swizzle on the source side, LDS stays lane-linear).
+// Row overruns are clamped (the rows are never stored); the K tail relies on B's zero padding.
+// =========================================================================================
+__device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ int swzP(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
+
+constexpr int DBM = 256;   // rows per workgroup of the DMA kernel: 8 waves x 32 rows, every wave spans all N columns
+
+template <int EPI, int NT16>
+__global__ __launch_bounds__(WTHR) void gemm_nt_dma_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
+                                                           int ldb, int M, int Ntot, int K, EpiArgs ep, int nchunks) {
+  constexpr int WBN = NT16 * 16;
+  constexpr int NP = DBM / 16 + NT16;            // 1-KB DMA pieces per stage (A rows, then B rows)
+  constexpr int PB = NP / 8, PX = NP % 8;        // a wave issues PB (+1 if wid < PX) pieces per stage
+  constexpr int STAGE = NP * 1024;               // bytes per ring stage
+  constexpr int NS = (4 * STAGE <= 150 * 1024) ? 4 : 3;
+  constexpr int SCW = WBN + 4;
+  constexpr int AB = DBM * 64;                   // byte offset of the B tile inside a stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sC = reinterpret_cast<float*>(smem);
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int bid = blockIdx.x, per = 8 * nchunks;
+  const int mt = (bid / per) * 8 + (bid & 7), nch = (bid >> 3) % nchunks;
+  const int m0 = mt * DBM, nbase = nch * WBN;
+  if (m0 >= M) return;
+  const int N = min(WBN, Ntot - nbase);
+  constexpr int HN = (NT16 + 1) / 2;             // column tiles per wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
+  const bool extra = wid < PX;                   // wave-uniform
+  const int pfirst = wid * PB + min(wid, PX);    // first piece of this wave
+
+  // this wave's pieces: per-lane source row pointer; A pieces clamp the K tail, B relies on zero padding
+  const bf16_t* src[PB + 1];
+  bool isA[PB + 1];
+  const int prow = lane >> 2, c8 = ((lane & 3) ^ swzP(prow)) * 8;   // (16p + prow) >> 2 & 3 == prow >> 2 & 3
+#pragma unroll
+  for (int t = 0; t < PB + 1; ++t) {
+    const int p = pfirst + t;
+    if (p < DBM / 16) {
+      src[t] = A + (size_t)min(m0 + 16 * p + prow, M - 1) * lda + c8;
+      isA[t] = true;
+    } else {
+      src[t] = B + (size_t)min(nbase + 16 * (p - DBM / 16) + prow, Ntot - 1) * ldb + c8;
+      isA[t] = false;
+    }
+  }
+  auto issue = [&](int stage, int k0) {
+#pragma unroll
+    for (int t = 0; t < PB + 1; ++t) {
+      if (t < PB || extra) {
+        const int kk = isA[t] ? min(k0, K - 8 - c8) : k0;   // K tail of A: re-read a valid chunk (B is zero there)
+        dma16(src[t] + kk, lds0 + stage * STAGE + (pfirst + t) * 1024);
+      }
+    }
+  };
+
+  // wave tile = 64 rows x HN*16 columns: 4 A fragments are reused by every B fragment (4 MFMAs per LDS read)
+  f32x4 acc[4][HN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < HN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment byte offsets inside a stage (loop invariant)
+  const int fr = lane & 15, g = lane >> 4;
+  int offA[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wm * 64 + i * 16 + fr;
+    offA[i] = r * 64 + ((g ^ swzP(r)) << 4);
+  }
+  // B tile row (wn*HN + j)*16 + fr : + j*1024 per column tile (16 rows x 64 B; the swizzle has period 16 rows)
+  const int offB = AB + wn * HN * 1024 + fr * 64 + ((g ^ swzP(fr)) << 4);
+
+  const int nk = (K + BK - 1) / BK;
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) issue(s, s * BK);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int rem = min(NS - 2, nk - 1 - kt);    // stages issued after stage kt that may stay in flight
+    if (extra) {
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PB + 1)) : "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PB) : "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
+    const char* st = smem + (kt % NS) * STAGE;
+    bf16x8 af[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + offA[i]);
+#pragma unroll
+    for (int j = 0; j < HN; ++j) {
+      if (wn * HN + j < NT16) {
+        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(st + offB + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // epilogue: 32 rows at a time through the fp32 LDS tile (pass p = rows 32p..32p+31 = wave row wm = p>>1, tiles 2(p&1), +1)
+#pragma unroll 1
+  for (int pass = 0; pass < 8; ++pass) {
+    if (pass) __syncthreads();
+    if (wm == (pass >> 1)) {
+#pragma unroll
+      for (int j = 0; j < HN; ++j) {
+        const int jt = wn * HN + j;
+        if (jt < NT16) {
+          const int col = jt * 16 + (lane & 15);
+          float bv = 0.f;
+          if ((EPI == EPI_STORE || EPI == EPI_STORE_TANH) && ep.bias != nullptr && col < N) bv = ep.bias[nbase + col];
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              // static accumulator index: both candidate tiles are written from a select
+              float v = ((pass & 1) ? acc[2 + i2][j][r] : acc[i2][j][r]) + bv;
+              if (EPI == EPI_STORE_TANH) v = tanhf(v);
+              sC[(i2 * 16 + (lane >> 4) * 4 + r) * SCW + col] = v;
+            }
+        }
+      }
+    }
+    __syncthreads();
+    for (int u = tid; u < 32 * (WBN / 4); u += WTHR) {
+      const int row = u / (WBN / 4), c0 = (u % (WBN / 4)) * 4;
+      const int m = m0 + pass * 32 + row;
+      if (m < M && c0 < N) emit4<EPI>(ep, m, nbase + c0, Ntot, *reinterpret_cast<const f32x4*>(sC + row * SCW + c0));
+    }
+  }
+}
+
+template <int EPI, int NT16>
+int launch_nt_dma_t(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
+  constexpr int NP = DBM / 16 + NT16, STAGE = NP * 1024, NS = (4 * STAGE <= 150 * 1024) ? 4 : 3;
+  constexpr size_t ring = (size_t)NS * STAGE, epi = (size_t)32 * (NT16 * 16 + 4) * sizeof(float);
+  constexpr size_t smem = ring > epi ? ring : epi;
+  auto kern = gemm_nt_dma_kernel<EPI, NT16>;
+  NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  const int tilesM = (M + DBM - 1) / DBM, nchunks = (N + NT16 * 16 - 1) / (NT16 * 16);
+  const int grid = ((tilesM + 7) / 8) * 8 * nchunks;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(WTHR), smem, stream, (const bf16_t*)A.base, A.ld, (const bf16_t*)B, ldb, M, N, K, ep,
+                     nchunks);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+template <int NT16>
+int launch_nt_dma_e(const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi, const EpiArgs& ep, hipStream_t s) {
+  switch (epi) {
+    case EPI_STORE: return launch_nt_dma_t<EPI_STORE, NT16>(A, B, ldb, M, N, K, ep, s);
+    case EPI_STORE_TANH: return launch_nt_dma_t<EPI_STORE_TANH, NT16>(A, B, ldb, M, N, K, ep, s);
+    case EPI_POOLBWD: return launch_nt_dma_t<EPI_POOLBWD, NT16>(A, B, ldb, M, N, K, ep, s);
+    case EPI_SCATTER: return launch_nt_dma_t<EPI_SCATTER, NT16>(A, B, ldb, M, N, K, ep, s);
+  }
+  nr_set_error("gemm_nt_dma: bad epilogue %d", epi);
   return NR_ERR_ARG;
 }
 
@@ -883,6 +1102,7 @@ template <typename T, int KIND>
 int launch_nt_k(const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi, const EpiArgs& ep, hipStream_t s) {
   switch (epi) {
     case EPI_STORE: return launch_nt_t<T, KIND, EPI_STORE>(A, B, ldb, M, N, K, ep, s);
+    case EPI_STORE_TANH: return launch_nt_t<T, KIND, EPI_STORE_TANH>(A, B, ldb, M, N, K, ep, s);
     case EPI_POOLBWD: return launch_nt_t<T, KIND, EPI_POOLBWD>(A, B, ldb, M, N, K, ep, s);
     case EPI_SCATTER: return launch_nt_t<T, KIND, EPI_SCATTER>(A, B, ldb, M, N, K, ep, s);
   }
@@ -897,6 +1117,7 @@ int launch_nt_d(const RowSrc& A, const void* B, int ldb, int M, int N, int K, in
     case ROWS_GATHER: return launch_nt_k<T, ROWS_GATHER>(A, B, ldb, M, N, K, epi, ep, s);
     case ROWS_IM2COL3:
       if (epi == EPI_STORE) return launch_nt_t<T, ROWS_IM2COL3, EPI_STORE>(A, B, ldb, M, N, K, ep, s);
+      if (epi == EPI_STORE_TANH) return launch_nt_t<T, ROWS_IM2COL3, EPI_STORE_TANH>(A, B, ldb, M, N, K, ep, s);
       break;
   }
   nr_set_error("gemm_nt: unsupported row source %d / epilogue %d", A.kind, epi);
@@ -959,12 +1180,25 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
   NR_CHECK_ARG(K % ch == 0 && ldb % ch == 0 && A.ld % ch == 0, "gemm_nt: K=%d ldb=%d lda=%d must be multiples of %d", K, ldb, A.ld, ch);
   NR_CHECK_ARG(((uintptr_t)A.base & 15) == 0 && ((uintptr_t)B & 15) == 0, "gemm_nt: operands must be 16-byte aligned");
   if (epi != EPI_SCATTER) NR_CHECK_ARG(ep.ldc % 4 == 0 && ((uintptr_t)ep.C & 15) == 0, "gemm_nt: output ld %d / alignment", ep.ldc);
+  if (epi == EPI_STORE && ep.act_tanh) epi = EPI_STORE_TANH;
+  // Kernel choice (bf16, dense A), from per-shape measurements on MI355X (tools/gemm_probe.py):
+  //   K >= 512            : LDS-DMA ring kernel (long k loop: the prefetch ring pays, A read once)
+  //   N <= 208, small K   : "wide" kernel, all N columns per workgroup (A read once)
+  //   otherwise           : 128 x 128 tiled kernel with the packed bf16 epilogue
   static const bool no_wide = getenv("NR_NT_NOWIDE") != nullptr;
-  if (!no_wide && dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0 && N <= 400 && ep.rows_out == nullptr) {
+  static const bool no_dma = getenv("NR_NT_NODMA") != nullptr;
+  const int kr32 = (K + 31) / 32 * 32;
+  const bool dense_bf16 = dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0 && ep.rows_out == nullptr;
+  if (dense_bf16 && !no_dma && K >= 512 && ldb >= kr32 && A.ld >= K) {
+    // B must be zero beyond K up to the next multiple of 32 (nr_cast_pad with such an ld guarantees it)
+    NrProfScope ps(stream, "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d]", epi, M, N, K);
+    const int c13 = ((N + 207) / 208) * 13, c20 = ((N + 319) / 320) * 20;   // fewer padded column tiles wins
+    if (c13 < c20) return launch_nt_dma_e<13>(A, B, ldb, M, N, K, epi, ep, stream);
+    return launch_nt_dma_e<20>(A, B, ldb, M, N, K, epi, ep, stream);
+  }
+  if (dense_bf16 && !no_wide && N <= 208) {
     NrProfScope ps(stream, "gemm_nt_wide[bf16,epi=%d,M=%d,N=%d,K=%d]", epi, M, N, K);
-    if (N <= 208) return launch_nt_wide_e<13>(A, B, ldb, M, N, K, epi, ep, stream);
-    if (N <= 320) return launch_nt_wide_e<20>(A, B, ldb, M, N, K, epi, ep, stream);
-    return launch_nt_wide_e<25>(A, B, ldb, M, N, K, epi, ep, stream);
+    return launch_nt_wide_e<13>(A, B, ldb, M, N, K, epi, ep, stream);
   }
   NrProfScope ps(stream, "gemm_nt[%s,rows=%d,epi=%d,M=%d,N=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", A.kind, epi, M, N, K);
   return dtype == NR_BF16 ? launch_nt_d<bf16_t>(A, B, ldb, M, N, K, epi, ep, stream)

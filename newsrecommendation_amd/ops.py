@@ -63,7 +63,8 @@ def pack(src: torch.Tensor, code: int, transpose: bool = False, ld: Optional[int
         src = src.float().contiguous()
     rows, cols = src.shape
     drows, dcols = (cols, rows) if transpose else (rows, cols)
-    ld = ld or round_up(dcols, chunk(code))
+    # bf16: leading dimension rounded up to 32 and zero padded, so the LDS-DMA GEMM can run whole 32-deep k-steps
+    ld = ld or round_up(dcols, 32 if code == NR_BF16 else chunk(code))
     dst = torch.empty(drows, ld, dtype=torch_dtype(code), device=src.device)
     check(_lib.lib().nr_cast_pad(ptr(src), rows, cols, cols, ptr(dst), ld, code, int(transpose), _stream()), "nr_cast_pad")
     return dst
