@@ -36,9 +36,12 @@ def test_nrms_train_mode_matches_oracle_with_same_masks(tag, dt, tol, gtol):
     lo, so, go = oracle_run(tag, z, cfg, sd, keep=keep)
     assert_close(loss, lo, tol, name="loss")
     assert_close(score, so, tol, name="score")
+    # bf16: absolute floor 5e-5 (d W_K.bias is analytically ~0 -- a constant key shift leaves the softmax unchanged --
+    # so only bf16 rounding noise of the dK entries remains there)
+    atol = 1e-6 if dt == "fp32" else 5e-5
     for name, p in m.named_parameters():
         if p.requires_grad and name in go:
-            assert_close(p.grad, go[name], 1e-6, gtol, name="d" + name)
+            assert_close(p.grad, go[name], atol, gtol, name="d" + name)
     assert float(dict(m.named_parameters())[table_key(tag)].grad[0].abs().max()) == 0.0
 
 

@@ -79,7 +79,7 @@ def test_bf16_forward_backward_vs_oracle(tag):
     assert_close(score, so, 3e-2, name="score")
     for name, p in m.named_parameters():
         if p.requires_grad and name in go:
-            assert_close(p.grad, go[name], 1e-5, 6e-2, name="d" + name)
+            assert_close(p.grad, go[name], 5e-5, 6e-2, name="d" + name)
 
 
 def test_state_dict_surface():
