@@ -1,0 +1,154 @@
+"""Train / eval loops with the shape of the reference's src/main.py (train :22-142, test :145-277).
+
+File parsing of news.tsv and the title-embedding generation are out of scope: the loops
+take the arrays those steps produce (`news_index`, `news_combined`, `embedding_matrix`).  Everything from the
+sharded behaviours files onward follows the reference: DatasetTrain/DataLoader, forward, acc, backward (+ DDP
+all-reduce), Adam, logging, checkpoint dict layout; eval encodes the whole corpus once, keeps the news-vector
+table ON DEVICE, gathers history / candidate vectors there and scores there (the reference round-trips every
+vector through numpy, main.py:195-253), then reduces the metric sums to rank 0 (main.py:269-273).
+"""
+import importlib
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+
+from . import metrics, ops
+from .data import DatasetTest, DatasetTrain
+
+
+def acc(y_true, y_hat):
+    """src/utils.py:36-40."""
+    y_hat = torch.argmax(y_hat, dim=-1)
+    return (y_true == y_hat).sum().float() / y_true.shape[0]
+
+
+def build_model(args, embedding_matrix, n_category=0, n_subcategory=0):
+    """src/main.py:63-64: the model module is chosen by name."""
+    module = importlib.import_module(f"newsrecommendation_amd.model.{args.model}")
+    return module.Model(args, embedding_matrix, n_category, n_subcategory)
+
+
+def checkpoint_dict(model, category_dict=None, subcategory_dict=None):
+    """src/main.py:118-142 layout; DDP's 'module.' prefix stripped."""
+    sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in model.state_dict().items()}
+    return {"model_state_dict": sd, "category_dict": category_dict or {}, "subcategory_dict": subcategory_dict or {}}
+
+
+def train(rank, args, news_index, news_combined, embedding_matrix, category_dict=None, subcategory_dict=None,
+          max_steps=None, log=logging.info):
+    """One rank of the training job (src/main.py:22-142).  rank=None: single process.  Returns the loss history."""
+    is_distributed = rank is not None
+    rank = rank or 0
+    device = torch.device("cuda", rank if is_distributed else torch.cuda.current_device())
+    torch.cuda.set_device(device)
+    model = build_model(args, embedding_matrix, len(category_dict or {}), len(subcategory_dict or {}))
+    if getattr(args, "load_ckpt_name", None):
+        ckpt = torch.load(os.path.join(args.model_dir, args.load_ckpt_name), map_location="cpu", weights_only=True)
+        model.load_state_dict(ckpt["model_state_dict"])
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)       # main.py:76
+    model = model.to(device)
+    net = model
+    if is_distributed:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index])   # main.py:82
+    data_file = os.path.join(args.train_data_dir, f"behaviors_np{args.npratio}_{rank}.tsv")
+    dataset = DatasetTrain(data_file, news_index, news_combined, args)
+    dataloader = DataLoader(dataset, batch_size=args.batch_size)
+    losses = []
+    step = 0
+    for ep in range(getattr(args, "start_epoch", 0), args.epochs):
+        loss_sum, acc_sum, t0 = 0.0, 0.0, time.time()
+        net.train()
+        for cnt, (history, history_mask, candidate, label) in enumerate(dataloader):
+            history = history.to(device, non_blocking=True)
+            history_mask = history_mask.to(device, non_blocking=True)
+            candidate = candidate.to(device, non_blocking=True)
+            label = label.to(device, non_blocking=True)
+            bz_loss, y_hat = net(history, history_mask, candidate, label)
+            optimizer.zero_grad()
+            bz_loss.backward()
+            optimizer.step()
+            loss_sum += float(bz_loss.detach())
+            acc_sum += float(acc(label, y_hat))
+            losses.append(float(bz_loss.detach()))
+            step += 1
+            if cnt % args.log_steps == 0:
+                log("[{}][{}] Ed: {}, train_loss: {:.5f}, acc: {:.5f}".format(
+                    ep, rank, cnt * args.batch_size, loss_sum / (cnt + 1), acc_sum / (cnt + 1)))
+            if max_steps is not None and step >= max_steps:
+                break
+        if rank == 0 and getattr(args, "model_dir", None):
+            os.makedirs(args.model_dir, exist_ok=True)
+            torch.save(checkpoint_dict(net, category_dict, subcategory_dict), os.path.join(args.model_dir, f"epoch-{ep + 1}.pt"))
+        if max_steps is not None and step >= max_steps:
+            break
+    return model, losses
+
+
+@torch.no_grad()
+def encode_news(model, news_combined, batch_size, device):
+    """Full-corpus encode (src/main.py:185-198); the [N+1, news_dim] table stays on the device."""
+    out = []
+    ids = torch.as_tensor(news_combined, dtype=torch.int32)
+    for i in range(0, ids.shape[0], batch_size):
+        out.append(model.news_encoder(ids[i:i + batch_size].to(device)))
+    return torch.cat(out, dim=0)
+
+
+@torch.no_grad()
+def test(rank, args, model, news_index, news_combined, log=logging.info):
+    """One rank of the evaluation job (src/main.py:145-277) on `behaviors_{rank}.tsv`.
+    Returns (n_impressions, [AUC, MRR, nDCG@5, nDCG@10] means over scored impressions) after the cross-rank reduce."""
+    is_distributed = rank is not None
+    rank = rank or 0
+    device = next(model.parameters()).device
+    model.eval()
+    news_vecs = encode_news(model, news_combined, args.batch_size, device)            # [N+1, news_dim] on device
+    data_file = os.path.join(args.test_data_dir, f"behaviors_{rank}.tsv")
+    ident = np.arange(news_vecs.shape[0], dtype=np.int64)[:, None]                    # dataset yields news INDICES
+    dataset = DatasetTest(data_file, news_index, ident, args)
+    sums, n_scored, n_seen = np.zeros(4), 0, 0
+    batch = []
+
+    def flush():
+        nonlocal sums, n_scored
+        if not batch:
+            return
+        hist = torch.as_tensor(np.stack([b[0][:, 0] for b in batch]), dtype=torch.int32, device=device)
+        mask = torch.as_tensor(np.stack([b[1] for b in batch]), dtype=torch.float32, device=device)
+        log_vecs = ops.embed_gather(news_vecs, hist)                                  # [B, H, news_dim], device gather
+        user_vecs = model.user_encoder(log_vecs, mask)                                # main.py:247
+        cand = np.concatenate([b[2][:, 0] for b in batch])
+        imp_of = np.concatenate([np.full(len(b[2]), i, dtype=np.int32) for i, b in enumerate(batch)])
+        score = ops.score_eval(news_vecs, torch.as_tensor(cand, device=device), torch.as_tensor(imp_of, device=device),
+                               user_vecs).cpu().numpy()                               # main.py:253, one launch
+        off = 0
+        for b in batch:
+            label = b[3]
+            s = score[off:off + len(label)]
+            off += len(label)
+            if label.mean() == 0 or label.mean() == 1:                                # main.py:250
+                continue
+            sums += [metrics.roc_auc_score(label, s), metrics.mrr_score(label, s), metrics.ndcg_score(label, s, 5),
+                     metrics.ndcg_score(label, s, 10)]
+            n_scored += 1
+        batch.clear()
+
+    for item in dataset:
+        batch.append(item)
+        n_seen += 1
+        if len(batch) == args.batch_size:
+            flush()
+    flush()
+    if is_distributed:
+        t = torch.tensor([n_scored, *sums], dtype=torch.float64, device=device)
+        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)                                   # main.py:270-273, one message
+        n_scored, sums = int(t[0].item()), t[1:].cpu().numpy()
+    means = sums / max(n_scored, 1)
+    if rank == 0:
+        log("[*] {} samples: {}".format(n_scored, "\t".join("{:0.2f}".format(x * 100) for x in means)))
+    return n_seen, means

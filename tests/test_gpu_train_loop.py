@@ -1,0 +1,96 @@
+"""GPU, BASELINE config[0]: a 1k-impression synthetic MIND set pushed through the package's own sharder and
+datasets, then the train loop (fp32, dropout 0 so the trajectory is defined) against the oracle stepping the
+same batches with torch-CPU Adam, and the eval loop (device-side gather + scoring) against the oracle's
+per-impression numpy path.  Tolerances: loss trajectory 2e-3 abs over 15 steps; metric means 2e-4."""
+import os
+import random
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nr_oracle as O
+from newsrecommendation_amd import data as D, train as TR
+
+pytestmark = pytest.mark.gpu
+
+
+def _synth(tmp, n_news=120, vocab=300, n_imp=1000, seed=5):
+    rnd = random.Random(seed)
+    T = 12
+    news_ids = [f"N{i}" for i in range(1, n_news + 1)]
+    news_index = {nid: i + 1 for i, nid in enumerate(news_ids)}
+    g = torch.Generator().manual_seed(seed)
+    news_combined = torch.randint(1, vocab, (n_news + 1, T), generator=g, dtype=torch.int32)
+    news_combined[0] = 0
+    for r in range(1, n_news + 1):
+        news_combined[r, rnd.randint(3, T):] = 0
+    table = (torch.randn(vocab, 16, generator=g) * 0.4)
+    table[0] = 0
+    lines = []
+    for i in range(n_imp):
+        hist = " ".join(rnd.choice(news_ids) for _ in range(rnd.randint(0, 12)))
+        imps = [f"{rnd.choice(news_ids)}-{1 if rnd.random() < 0.25 else 0}" for _ in range(rnd.randint(2, 9))]
+        lines.append("\t".join([str(i + 1), "U1", "t", hist, " ".join(imps)]) + "\n")
+    for sub in ("train", "test"):
+        os.makedirs(os.path.join(tmp, sub), exist_ok=True)
+        with open(os.path.join(tmp, sub, "behaviors.tsv"), "w") as f:
+            f.writelines(lines if sub == "train" else lines[:200])
+    args = SimpleNamespace(model="NRMS", num_words_title=T, user_log_length=8, npratio=4, word_embedding_dim=16, news_dim=24,
+                           num_attention_heads=6, news_query_vector_dim=8, user_query_vector_dim=8, drop_rate=0.0,
+                           user_log_mask=False, freeze_embedding=False, use_category=False, use_subcategory=False,
+                           category_emb_dim=4, compute_dtype="fp32", lr=1e-3, batch_size=32, epochs=1, log_steps=1000,
+                           train_data_dir=os.path.join(tmp, "train"), test_data_dir=os.path.join(tmp, "test"), model_dir=None)
+    return args, news_index, news_combined.numpy(), table.numpy()
+
+
+def test_train_loop_tracks_oracle_and_eval_matches(tmp_path):
+    args, news_index, news_combined, table = _synth(str(tmp_path))
+    n = D.prepare_training_data(args.train_data_dir, 1, args.npratio, seed=0)
+    assert n > 100
+    steps = 15
+    torch.manual_seed(0)
+    random.seed(0)
+    model, losses = TR.train(None, args, news_index, news_combined, table, max_steps=steps, log=lambda *_: None)
+    assert len(losses) == steps
+
+    # oracle trajectory: same initial parameters, same batches (same label RNG), torch-CPU Adam
+    torch.manual_seed(0)
+    init = TR.build_model(args, table).state_dict()
+    params = {k: v.detach().clone().float().requires_grad_(True) for k, v in init.items()}
+    opt = torch.optim.Adam(params.values(), lr=args.lr)
+    random.seed(0)
+    ds = D.DatasetTrain(os.path.join(args.train_data_dir, f"behaviors_np{args.npratio}_0.tsv"), news_index, news_combined, args)
+    ref = []
+    for cnt, (h, m, c, l) in enumerate(torch.utils.data.DataLoader(ds, batch_size=args.batch_size)):
+        if cnt == steps:
+            break
+        loss, _ = O.nrms_forward(h, m, c, l, params, args)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ref.append(float(loss))
+    assert max(abs(a - b) for a, b in zip(losses, ref)) < 2e-3, (losses, ref)
+    assert losses[-1] < losses[0]
+
+    # eval loop vs the oracle's per-impression path on the trained weights
+    D.prepare_testing_data(args.test_data_dir, 1)
+    args_eval = SimpleNamespace(**vars(args))
+    args_eval.user_log_mask = True           # demo.sh:26 evaluates with the masked user encoder
+    model.args.user_log_mask = True
+    model.user_encoder.args.user_log_mask = True
+    n_seen, means = TR.test(None, args_eval, model, news_index, news_combined, log=lambda *_: None)
+    sd = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
+    nv = O.nrms_news_encoder(torch.from_numpy(news_combined), sd, args_eval)
+    sums, cnt = np.zeros(4), 0
+    for line in open(os.path.join(args.test_data_dir, "behaviors_0.tsv")):
+        hist, mask, cand, labels = O.test_line_to_indices(line, news_index, args.user_log_length)
+        uv = O.nrms_user_encoder(nv[hist][None], torch.from_numpy(mask)[None], sd, args_eval)[0]
+        if labels.mean() in (0, 1):
+            continue
+        s = (nv[cand] @ uv).numpy()
+        sums += [O.auc_score(labels, s), O.mrr_score(labels, s), O.ndcg_score(labels, s, 5), O.ndcg_score(labels, s, 10)]
+        cnt += 1
+    assert n_seen == 200 and cnt > 50
+    assert np.allclose(means, sums / cnt, atol=2e-4), (means, sums / cnt)
