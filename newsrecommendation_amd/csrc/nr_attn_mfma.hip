@@ -523,10 +523,15 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
 
-  for (long p0 = (long)blockIdx.x * AW; p0 < total; p0 += (long)gridDim.x * AW) {
-    const long p = p0 + wid;
-    const bool active = p < total;
-    const int seq = active ? (int)(p / a.heads) : 0, head = active ? (int)(p % a.heads) : 0;
+  // One workgroup walks ALL heads of a sequence (AW heads at a time) before moving on: the sequence's Q|K|V rows
+  // (a 128-byte line spans 3.2 heads) are then re-read from this CU's L1/L2 instead of by workgroups on other XCDs.
+  const int hgroups = (a.heads + AW - 1) / AW;
+  for (long sb = blockIdx.x; sb < a.n; sb += gridDim.x)
+  for (int hgi = 0; hgi < hgroups; ++hgi) {
+    const long it = sb * hgroups + hgi;
+    const int seq = (int)(it / hgroups), hraw = (int)(it % hgroups) * AW + wid;
+    const bool active = hraw < a.heads;
+    const int head = active ? hraw : 0;
     const size_t row0 = (size_t)seq * L;
     const bf16_t* src = qkv + row0 * 3 * N + head * d;
     const int Ls = active ? L : 0;                       // inactive waves stage zeros and store nothing
@@ -586,10 +591,13 @@ __global__ __launch_bounds__(AW * 64) void bwd_kernel(AttnMArgs a) {
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
 
-  for (long p0 = (long)blockIdx.x * AW; p0 < total; p0 += (long)gridDim.x * AW) {
-    const long p = p0 + wid;
-    const bool active = p < total;
-    const int seq = active ? (int)(p / a.heads) : 0, head = active ? (int)(p % a.heads) : 0;
+  const int hgroups = (a.heads + AW - 1) / AW;
+  for (long sb = blockIdx.x; sb < a.n; sb += gridDim.x)
+  for (int hgi = 0; hgi < hgroups; ++hgi) {
+    const long it = sb * hgroups + hgi;
+    const int seq = (int)(it / hgroups), hraw = (int)(it % hgroups) * AW + wid;
+    const bool active = hraw < a.heads;
+    const int head = active ? hraw : 0;
     const size_t row0 = (size_t)seq * L;
     const int Ls = active ? L : 0;
     const bf16_t* src = qkv + row0 * 3 * N + head * d;
@@ -672,8 +680,7 @@ __global__ __launch_bounds__(AW * 64) void bwd_kernel(AttnMArgs a) {
 }
 
 int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
-  const long total = (long)a.n * a.heads;
-  long blocks = (total + AW - 1) / AW;
+  long blocks = a.n;   // one workgroup per sequence (grid-stride beyond the cap), all heads inside
   const size_t smem = bwd ? AW * (4 * IMG * sizeof(bf16_t) + 128 * sizeof(float)) : AW * (3 * IMG * sizeof(bf16_t) + 32 * sizeof(float));
   const long cap = 256L * 4 * 4;
   if (blocks > cap) blocks = cap;

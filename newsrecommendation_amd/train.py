@@ -100,9 +100,10 @@ def encode_news(model, news_combined, batch_size, device):
 
 
 @torch.no_grad()
-def test(rank, args, model, news_index, news_combined, log=logging.info):
+def test(rank, args, model, news_index, news_combined, log=logging.info, collect_scores=None):
     """One rank of the evaluation job (src/main.py:145-277) on `behaviors_{rank}.tsv`.
-    Returns (n_impressions, [AUC, MRR, nDCG@5, nDCG@10] means over scored impressions) after the cross-rank reduce."""
+    Returns (n_impressions, [AUC, MRR, nDCG@5, nDCG@10] means over scored impressions) after the cross-rank reduce.
+    `collect_scores`: optional list that receives (labels, scores) of every impression of this rank."""
     is_distributed = rank is not None
     rank = rank or 0
     device = next(model.parameters()).device
@@ -131,6 +132,8 @@ def test(rank, args, model, news_index, news_combined, log=logging.info):
             label = b[3]
             s = score[off:off + len(label)]
             off += len(label)
+            if collect_scores is not None:
+                collect_scores.append((label, s))
             if label.mean() == 0 or label.mean() == 1:                                # main.py:250
                 continue
             sums += [metrics.roc_auc_score(label, s), metrics.mrr_score(label, s), metrics.ndcg_score(label, s, 5),
