@@ -1,0 +1,145 @@
+"""GPU: size-independent properties at BASELINE.json's full per-GPU sizes (B=512 -> 28 160 titles, 844 800 token
+rows), where the CPU oracle would take minutes, plus the reference's documented edge cases.
+
+  * GEMM building blocks: linearity in A, agreement of the bf16 MFMA path with an fp64 torch product on sampled
+    rows/columns, weight-gradient GEMM == sum over row blocks (split invariance) and db == column sums.
+  * attention: all-ones key mask == no mask; all-zero mask -> exactly 0 output; permuting the tokens
+    of a title permutes its outputs (no positional term).
+  * pooling: permutation invariance over tokens; all-zero mask -> exactly 0.
+  * embedding: gather -> scatter-add round trip counts ids, padding id 0 receives nothing.
+"""
+import pytest
+import torch
+
+from newsrecommendation_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+M_FULL = 512 * 55 * 30
+
+
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+def test_gemm_nt_full_size_sampled_against_fp64_and_linearity():
+    g = torch.Generator(device=DEV).manual_seed(0)
+    M, N, K = M_FULL, 1200, 304
+    a = _bf(torch.randn(M, K, device=DEV, generator=g) * 0.5)
+    wfull = torch.zeros(N, 320, device=DEV, dtype=torch.bfloat16)
+    wfull[:, :K] = _bf(torch.randn(N, K, device=DEV, generator=g) * 0.1)
+    w = wfull[:, :K]
+    c = ops.gemm_nt(a, w)
+    rows = torch.randint(0, M, (2048,), device=DEV, generator=g)
+    ref = a[rows].double() @ w.double().t()
+    err = (c[rows].double() - ref).abs().max().item()
+    assert err <= 0.03, err                                   # bf16 output rounding of values up to ~5
+    # last rows / last columns (tile tails) exactly as well
+    assert (c[-5:].double() - a[-5:].double() @ w.double().t()).abs().max().item() <= 0.03
+    # linearity: (2a) W^T == 2 (a W^T) exactly (power-of-two scaling commutes with every rounding)
+    c2 = ops.gemm_nt(_bf(a.float() * 2), w)
+    assert torch.equal(c2.float(), c.float() * 2)
+
+
+def test_gemm_tn_full_size_split_invariance_and_bias_grad():
+    g = torch.Generator(device=DEV).manual_seed(1)
+    M, N, K = M_FULL, 200, 400
+    dc = _bf(torch.randn(M, N, device=DEV, generator=g) * 0.05)
+    a = _bf(torch.randn(M, K, device=DEV, generator=g) * 0.5)
+    dw, db = ops.gemm_tn(dc, a)
+    half = M // 2
+    dw1, db1 = ops.gemm_tn(dc[:half], a[:half])
+    dw2, db2 = ops.gemm_tn(dc[half:], a[half:])
+    scale = dw.abs().max().item()
+    assert (dw - (dw1 + dw2)).abs().max().item() <= 2e-5 * scale + 1e-3      # fp32 accumulation order only
+    assert (db - (db1 + db2)).abs().max().item() <= 1e-3 * db.abs().max().item() + 1e-3
+    ref_db = dc.double().sum(0)
+    assert (db.double() - ref_db).abs().max().item() <= 1e-3 * ref_db.abs().max().item() + 1e-2
+    cols = torch.arange(0, K, 37, device=DEV)
+    ref = dc.double().t() @ a[:, cols].double()
+    assert (dw[:, cols].double() - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_attention_mask_and_permutation_properties(dt):
+    code = ops.dtype_code(dt)
+    td = ops.torch_dtype(code)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    n, L, D, heads, dh = (2048 if dt == "bf16" else 256), 30, 304 if dt == "bf16" else 300, 20, 20
+    N = heads * dh
+    x = (torch.randn(n, L, D, device=DEV, generator=g) * 0.4).to(td)
+    ws = [torch.randn(N, D, device=DEV, generator=g) * 0.05 for _ in range(3)]
+    bs = [torch.randn(N, device=DEV, generator=g) * 0.05 for _ in range(3)]
+    args = (ws[0], bs[0], ws[1], bs[1], ws[2], bs[2])
+    y0 = ops.mhsa(x, *args, heads=heads, code=code)
+    ones = torch.ones(n, L, device=DEV)
+    y1 = ops.mhsa(x, *args, heads=heads, code=code, mask=ones)
+    assert torch.equal(y0, y1)                                              # all-ones mask == no mask
+    zeros = torch.zeros(n, L, device=DEV)
+    yz = ops.mhsa(x, *args, heads=heads, code=code, mask=zeros)
+    assert float(yz.float().abs().max()) == 0.0                             # fully masked -> exactly 0, not NaN
+    perm = torch.randperm(L, device=DEV, generator=g)
+    yp = ops.mhsa(x[:, perm].contiguous(), *args, heads=heads, code=code)
+    tol = 2e-5 if dt == "fp32" else 2e-2
+    assert (yp.float() - y0[:, perm].float()).abs().max().item() <= tol     # token permutation equivariance
+    # additive pooling: permutation invariance and the all-zero mask
+    q = 200
+    w1, b1 = torch.randn(q, N, device=DEV, generator=g) * 0.05, torch.randn(q, device=DEV, generator=g) * 0.05
+    w2, b2 = torch.randn(1, q, device=DEV, generator=g) * 0.1, torch.randn(1, device=DEV, generator=g) * 0.1
+    p0 = ops.additive_pool(y0, w1, b1, w2, b2, code)
+    pp = ops.additive_pool(y0[:, perm].contiguous(), w1, b1, w2, b2, code)
+    assert (p0 - pp).abs().max().item() <= (1e-5 if dt == "fp32" else 5e-3)
+    assert float(ops.additive_pool(y0, w1, b1, w2, b2, code, mask=zeros).abs().max()) == 0.0
+
+
+def test_full_batch_forward_bf16_tracks_fp32_and_is_deterministic():
+    """B=512 NRMS forward (eval): bf16 path vs the exact-fp32 path of the same library, twice for bit-reproducibility."""
+    import bench
+    from newsrecommendation_amd.model import NRMS
+    res = {}
+    for dt in ("fp32", "bf16"):
+        args = bench.make_args(dt)
+        torch.manual_seed(0)
+        g = torch.Generator().manual_seed(1)
+        table = torch.randn(3000, 300, generator=g) * 0.4
+        table[0] = 0
+        m = NRMS.Model(args, table.numpy()).to(DEV).eval()
+        hist, mask, cand, label = bench.synth_batches(args, 512, 3000, 1, 5, DEV)[0]
+        with torch.no_grad():
+            l1, s1 = m(hist, mask, cand, label)
+            l2, s2 = m(hist, mask, cand, label)
+        assert torch.equal(s1, s2) and torch.equal(l1, l2)                 # forward is deterministic
+        res[dt] = (float(l1), s1.float().cpu())
+    assert abs(res["fp32"][0] - res["bf16"][0]) <= 2e-2
+    assert (res["fp32"][1] - res["bf16"][1]).abs().max().item() <= 6e-2
+    assert torch.isfinite(res["bf16"][1]).all()
+
+
+def test_embedding_gather_scatter_roundtrip_and_padding_row():
+    g = torch.Generator(device=DEV).manual_seed(3)
+    V, D, n = 30000, 300, 844800 // 4
+    table = torch.randn(V, D, device=DEV, generator=g)
+    ids = torch.randint(0, V, (n,), device=DEV, generator=g, dtype=torch.int32)
+    out = ops.embed_gather(table, ids)
+    assert torch.equal(out, table[ids.long()])                              # row gather is a bit-exact copy
+    from newsrecommendation_amd import _lib
+    ones = torch.ones(n, 4, device=DEV)
+    acc = torch.zeros(V, 4, device=DEV)
+    _lib.check(_lib.lib().nr_embed_gather_bwd(ones.data_ptr(), 4, ids.data_ptr(), n, 1, 4, acc.data_ptr(), 4,
+                                              torch.cuda.current_stream().cuda_stream), "nr_embed_gather_bwd")
+    counts = torch.bincount(ids.long(), minlength=V).float()
+    counts[0] = 0                                                           # padding_idx row receives no gradient
+    assert torch.equal(acc[:, 0], counts) and torch.equal(acc[:, 3], counts)
+
+
+def test_empty_inputs_are_noops():
+    """n = 0 sequences: the C ABI returns OK without launching (ragged shards can produce empty tails)."""
+    code = ops.dtype_code("fp32")
+    x = torch.zeros(0, 5, 8, device=DEV)
+    w = torch.randn(8, 8, device=DEV)
+    b = torch.randn(8, device=DEV)
+    y = ops.mhsa(x, w, b, w, b, w, b, heads=2, code=code)
+    assert y.shape == (0, 5, 8)
+    out = ops.additive_pool(y, torch.randn(4, 8, device=DEV), torch.randn(4, device=DEV), torch.randn(1, 4, device=DEV),
+                            torch.randn(1, device=DEV), code)
+    assert out.shape == (0, 8)
