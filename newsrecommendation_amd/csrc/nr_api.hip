@@ -112,7 +112,7 @@ static int mhsa_check(const nr_mhsa_desc* d) {
                3 * d->heads * d->d_head, ch);
   NR_CHECK_ARG(d->ldx >= round_up(d->d_model, ch) && d->ldw >= round_up(d->d_model, ch),
                "mhsa: ldx=%d / ldw=%d must cover d_model=%d rounded up to %d", d->ldx, d->ldw, d->d_model, ch);
-  NR_CHECK_ARG(d->x && d->w_qkv && d->b_qkv, "mhsa: null operand");
+  NR_CHECK_ARG(d->n == 0 || (d->x && d->w_qkv && d->b_qkv), "mhsa: null operand");
   NR_CHECK_ARG(d->p_in >= 0.f && d->p_in < 1.f && d->p_out >= 0.f && d->p_out < 1.f, "mhsa: dropout p out of range");
   NR_CHECK_ARG((uint64_t)d->n * d->L * (uint64_t)(3 * d->heads * d->d_head) < 0xffffffffull, "mhsa: problem too large for 32-bit element counters");
   return NR_OK;
@@ -250,7 +250,7 @@ static int conv_rows(const nr_conv_desc* d, RowSrc* out) {
   NR_CHECK_ARG(d->n >= 0 && d->T >= 1 && d->D >= 1 && d->N >= 1 && d->Dp >= d->D && d->Dp % ch == 0,
                "conv1d: bad shape n=%d T=%d D=%d Dp=%d N=%d", d->n, d->T, d->D, d->Dp, d->N);
   NR_CHECK_ARG(d->N % ch == 0, "conv1d: N=%d must be a multiple of %d", d->N, ch);
-  NR_CHECK_ARG(d->table && d->ids && d->w_pack && d->bias && d->ids_stride >= 1, "conv1d: null operand");
+  NR_CHECK_ARG(d->n == 0 || (d->table && d->ids && d->w_pack && d->bias && d->ids_stride >= 1), "conv1d: null operand");
   NR_CHECK_ARG((uint64_t)d->n * d->T * (uint64_t)d->D < 0xffffffffull, "conv1d: problem too large for 32-bit element counters");
   RowSrc s = dense_rows(d->table, d->Dp, d->D);
   s.kind = ROWS_IM2COL3;
@@ -289,7 +289,7 @@ static int pool_check(const nr_pool_desc* d) {
                d->N, d->q);
   NR_CHECK_ARG(d->N % ch == 0 && d->q % ch == 0, "additive_pool: N=%d and q=%d must be multiples of %d for this dtype", d->N, d->q, ch);
   NR_CHECK_ARG(d->ldw1 >= d->N, "additive_pool: ldw1=%d < N=%d", d->ldw1, d->N);
-  NR_CHECK_ARG(d->x && d->w1 && d->b1 && d->w2 && d->b2, "additive_pool: null operand");
+  NR_CHECK_ARG(d->n == 0 || (d->x && d->w1 && d->b1 && d->w2 && d->b2), "additive_pool: null operand");
   return NR_OK;
 }
 
@@ -336,7 +336,7 @@ static int linear_rows(const nr_linear_desc* d, RowSrc* out) {
   NR_CHECK_ARG(d->M >= 0 && d->K >= 1 && d->N >= 1, "linear: bad shape M=%d K=%d N=%d", d->M, d->K, d->N);
   NR_CHECK_ARG(d->ldx >= round_up(d->K, ch) && d->ldw >= round_up(d->K, ch), "linear: ldx=%d / ldw=%d must cover K=%d rounded up to %d",
                d->ldx, d->ldw, d->K, ch);
-  NR_CHECK_ARG(d->x && d->w, "linear: null operand");
+  NR_CHECK_ARG(d->M == 0 || (d->x && d->w), "linear: null operand");
   RowSrc s = dense_rows(d->x, d->ldx, d->K);
   if (d->src_kind == NR_SRC_GATHER) {
     NR_CHECK_ARG(d->ids != nullptr && d->ids_stride >= 1, "linear: gather source without ids");
