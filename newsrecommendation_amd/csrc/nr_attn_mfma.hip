@@ -432,21 +432,30 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 __device__ __forceinline__ int ioff(int row, int col) { return row * 32 + ((((col >> 3) ^ ((row >> 2) & 3)) << 3) | (col & 7)); }
 __device__ __forceinline__ bf16x4 trd(const bf16_t* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p)); }
 
-template <bool DROP>
-__device__ __forceinline__ void stage(const bf16_t* __restrict__ src, size_t ld, int L, int d, bf16_t* img, int lane,
-                                      const DropCfg& drop, uint32_t eidx0, uint32_t erow) {
+// A head slice [L, d] travels global -> 4 x 8-byte registers per lane -> swizzled LDS image.  The two halves are
+// separate so the NEXT (sequence, head) slice can be in flight while the current one is being computed.
+struct Slice { bf16x4 v[4]; };
+__device__ __forceinline__ void slice_load(Slice& s, const bf16_t* __restrict__ src, size_t ld, int L, int d, int lane) {
   const int r = lane & 31, part = lane >> 5;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c = 4 * (2 * q + part);
-    bf16x4 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-    if (r < L && c < d) {
-      v = *reinterpret_cast<const bf16x4*>(src + (size_t)r * ld + c);
-      if (DROP && drop.thresh) {
-        const uint32_t e0 = eidx0 + (uint32_t)r * erow + (uint32_t)c;
+    s.v[q] = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (r < L && c < d) s.v[q] = *reinterpret_cast<const bf16x4*>(src + (size_t)r * ld + c);
+  }
+}
+template <bool DROP>
+__device__ __forceinline__ void slice_put(const Slice& s, int L, int d, bf16_t* img, int lane, const DropCfg& drop, uint32_t eidx0,
+                                          uint32_t erow) {
+  const int r = lane & 31, part = lane >> 5;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = nr_keep(drop.key, e0 + e, drop.thresh) ? (bf16_t)((float)v[e] * drop.scale) : (bf16_t)0.f;
-      }
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * (2 * q + part);
+    bf16x4 v = s.v[q];
+    if (DROP && drop.thresh && r < L && c < d) {
+      const uint32_t e0 = eidx0 + (uint32_t)r * erow + (uint32_t)c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = nr_keep(drop.key, e0 + e, drop.thresh) ? (bf16_t)((float)v[e] * drop.scale) : (bf16_t)0.f;
     }
     *reinterpret_cast<bf16x4*>(img + ioff(r, c)) = v;
   }
@@ -523,23 +532,48 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
 
-  // One workgroup walks ALL heads of a sequence (AW heads at a time) before moving on: the sequence's Q|K|V rows
-  // (a 128-byte line spans 3.2 heads) are then re-read from this CU's L1/L2 instead of by workgroups on other XCDs.
+  // One workgroup walks ALL heads of a sequence (AW heads at a time) before moving on; the slices of the NEXT item
+  // are loaded into registers while the current item is computed (the kernel is latency bound otherwise).
   const int hgroups = (a.heads + AW - 1) / AW;
-  for (long sb = blockIdx.x; sb < a.n; sb += gridDim.x)
-  for (int hgi = 0; hgi < hgroups; ++hgi) {
-    const long it = sb * hgroups + hgi;
-    const int seq = (int)(it / hgroups), hraw = (int)(it % hgroups) * AW + wid;
-    const bool active = hraw < a.heads;
-    const int head = active ? hraw : 0;
+  const long nitems = (long)a.n * hgroups;
+  auto item_of = [&](long k, int& seq, int& head, bool& active) {   // k-th item of this workgroup
+    const long sb = blockIdx.x + (k / hgroups) * (long)gridDim.x;
+    const int hraw = (int)(k % hgroups) * AW + wid;
+    active = sb < a.n && hraw < a.heads;
+    seq = sb < a.n ? (int)sb : 0;
+    head = active ? hraw : 0;
+  };
+  const long my_items = ((a.n - blockIdx.x + gridDim.x - 1) / gridDim.x) * hgroups;   // blockIdx.x < n by launch
+  (void)nitems;
+  Slice rq, rk, rv;
+  {
+    int seq, head; bool active;
+    item_of(0, seq, head, active);
+    const bf16_t* src = qkv + (size_t)seq * L * 3 * N + head * d;
+    const int Ls = active ? L : 0;
+    slice_load(rq, src, 3 * N, Ls, d, lane);
+    slice_load(rk, src + N, 3 * N, Ls, d, lane);
+    slice_load(rv, src + 2 * N, 3 * N, Ls, d, lane);
+  }
+  for (long k = 0; k < my_items; ++k) {
+    int seq, head; bool active;
+    item_of(k, seq, head, active);
     const size_t row0 = (size_t)seq * L;
-    const bf16_t* src = qkv + row0 * 3 * N + head * d;
     const int Ls = active ? L : 0;                       // inactive waves stage zeros and store nothing
-    stage<false>(src, 3 * N, Ls, d, sQ, lane, nodrop, 0, 0);
-    stage<false>(src + N, 3 * N, Ls, d, sK, lane, nodrop, 0, 0);
-    stage<false>(src + 2 * N, 3 * N, Ls, d, sV, lane, nodrop, 0, 0);
+    slice_put<false>(rq, Ls, d, sQ, lane, nodrop, 0, 0);
+    slice_put<false>(rk, Ls, d, sK, lane, nodrop, 0, 0);
+    slice_put<false>(rv, Ls, d, sV, lane, nodrop, 0, 0);
     if (lane < 32) sMask[lane] = (lane < Ls) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
     __syncthreads();
+    if (k + 1 < my_items) {
+      int seq2, head2; bool act2;
+      item_of(k + 1, seq2, head2, act2);
+      const bf16_t* src2 = qkv + (size_t)seq2 * L * 3 * N + head2 * d;
+      const int L2 = act2 ? L : 0;
+      slice_load(rq, src2, 3 * N, L2, d, lane);
+      slice_load(rk, src2 + N, 3 * N, L2, d, lane);
+      slice_load(rv, src2 + 2 * N, 3 * N, L2, d, lane);
+    }
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
@@ -592,21 +626,48 @@ __global__ __launch_bounds__(AW * 64) void bwd_kernel(AttnMArgs a) {
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
 
   const int hgroups = (a.heads + AW - 1) / AW;
-  for (long sb = blockIdx.x; sb < a.n; sb += gridDim.x)
-  for (int hgi = 0; hgi < hgroups; ++hgi) {
-    const long it = sb * hgroups + hgi;
-    const int seq = (int)(it / hgroups), hraw = (int)(it % hgroups) * AW + wid;
-    const bool active = hraw < a.heads;
-    const int head = active ? hraw : 0;
+  auto item_of = [&](long k, int& seq, int& head, bool& active) {
+    const long sb = blockIdx.x + (k / hgroups) * (long)gridDim.x;
+    const int hraw = (int)(k % hgroups) * AW + wid;
+    active = sb < a.n && hraw < a.heads;
+    seq = sb < a.n ? (int)sb : 0;
+    head = active ? hraw : 0;
+  };
+  const long my_items = ((a.n - blockIdx.x + gridDim.x - 1) / gridDim.x) * hgroups;
+  Slice rq, rk, rv, rg;
+  {
+    int seq, head; bool active;
+    item_of(0, seq, head, active);
+    const size_t r0 = (size_t)seq * L;
+    const bf16_t* src = qkv + r0 * 3 * N + head * d;
+    const int Ls = active ? L : 0;
+    slice_load(rq, src, 3 * N, Ls, d, lane);
+    slice_load(rk, src + N, 3 * N, Ls, d, lane);
+    slice_load(rv, src + 2 * N, 3 * N, Ls, d, lane);
+    slice_load(rg, dy + r0 * N + head * d, N, Ls, d, lane);
+  }
+  for (long k = 0; k < my_items; ++k) {
+    int seq, head; bool active;
+    item_of(k, seq, head, active);
     const size_t row0 = (size_t)seq * L;
     const int Ls = active ? L : 0;
-    const bf16_t* src = qkv + row0 * 3 * N + head * d;
-    stage<false>(src, 3 * N, Ls, d, sQ, lane, nodrop, 0, 0);
-    stage<false>(src + N, 3 * N, Ls, d, sK, lane, nodrop, 0, 0);
-    stage<false>(src + 2 * N, 3 * N, Ls, d, sV, lane, nodrop, 0, 0);
-    stage<true>(dy + row0 * N + head * d, N, Ls, d, sG, lane, a.drop, (uint32_t)(row0 * N + head * d), (uint32_t)N);
+    slice_put<false>(rq, Ls, d, sQ, lane, nodrop, 0, 0);
+    slice_put<false>(rk, Ls, d, sK, lane, nodrop, 0, 0);
+    slice_put<false>(rv, Ls, d, sV, lane, nodrop, 0, 0);
+    slice_put<true>(rg, Ls, d, sG, lane, a.drop, (uint32_t)(row0 * N + head * d), (uint32_t)N);
     if (lane < 32) sMask[lane] = (lane < Ls) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
     __syncthreads();
+    if (k + 1 < my_items) {
+      int seq2, head2; bool act2;
+      item_of(k + 1, seq2, head2, act2);
+      const size_t r2 = (size_t)seq2 * L;
+      const bf16_t* src2 = qkv + r2 * 3 * N + head2 * d;
+      const int L2 = act2 ? L : 0;
+      slice_load(rq, src2, 3 * N, L2, d, lane);
+      slice_load(rk, src2 + N, 3 * N, L2, d, lane);
+      slice_load(rv, src2 + 2 * N, 3 * N, L2, d, lane);
+      slice_load(rg, dy + r2 * N + head2 * d, N, L2, d, lane);
+    }
     f32x16 dst;  // dS^T (lane = query i)
     {
       f32x16 st, dpt;
