@@ -575,7 +575,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_kernel(const T* __restrict__ dC,
 //   X  tile, 320-B rows : chunk ^= 2*((row >> 3) & 1)   (rows are already skewed by 64 B)
 // =========================================================================================
 namespace tn2 {
-constexpr int TBN = 128, TBK = 160, TBM = 32;
+constexpr int TBN = 128, TBK = 160, TBM = 64;   // 64 rows of m (two 32-deep MFMA k-steps) per barrier
 constexpr int SCW = TBK + 4;
 constexpr size_t STAGE = (size_t)2 * TBM * (TBN + TBK) * sizeof(bf16_t);   // 36,864 B
 constexpr size_t EPI = (size_t)64 * SCW * sizeof(float);                     // 41,984 B
@@ -613,21 +613,22 @@ __global__ __launch_bounds__(NTHR) void gemm_tn2_kernel(const bf16_t* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
   const bool do_db = (db != nullptr) && (tk == 0);
 
-  uint4 ra[2], rb[3];
+  constexpr int NA = TBM * 16 / NTHR, NB = (TBM * 20 + NTHR - 1) / NTHR;
+  uint4 ra[NA], rb[NB];
   float colsum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) colsum[e] = 0.f;
 
   auto gload = [&](int mt) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int c = tid + i * NTHR, row = c >> 4, ch = c & 15;
       uint4 z = make_uint4(0, 0, 0, 0);
       if (mt + row < mend && n0 + ch * 8 < N) z = *reinterpret_cast<const uint4*>(dC + (size_t)(mt + row) * ldc + n0 + ch * 8);
       ra[i] = z;
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int c = tid + i * NTHR, row = c / 20, ch = c - row * 20;
       uint4 z = make_uint4(0, 0, 0, 0);
       if (c < TBM * 20 && mt + row < mend && k0 + ch * 8 < K) z = *reinterpret_cast<const uint4*>(X + (size_t)(mt + row) * ldx + k0 + ch * 8);
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn2_kernel(const bf16_t* __restrict
   };
   auto swrite = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const int c = tid + i * NTHR, row = c >> 4, ch = c & 15;
       *reinterpret_cast<uint4*>(sA + buf * TBM * TBN + row * TBN + swz_a(row, ch) * 8) = ra[i];
       if (do_db) {
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn2_kernel(const bf16_t* __restrict
       }
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < NB; ++i) {
       const int c = tid + i * NTHR, row = c / 20, ch = c - row * 20;
       if (c < TBM * 20) *reinterpret_cast<uint4*>(sB + buf * TBM * TBK + row * TBK + swz_b(row, ch) * 8) = rb[i];
     }
@@ -671,19 +672,21 @@ __global__ __launch_bounds__(NTHR) void gemm_tn2_kernel(const bf16_t* __restrict
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) gload(mbeg + (kt + 1) * TBM);
-    {
+#pragma unroll
+    for (int kh = 0; kh < TBM / 32; ++kh) {
       const bf16_t* a = sA + cur * TBM * TBN;
       const bf16_t* bq = sB + cur * TBM * TBK;
+      const int ra0 = 32 * kh + r0, ra1 = 32 * kh + r1;
       bf16x8 af[4], bf[5];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int chunk = (wm * 64 + i * 16) / 8 + (pp >> 1), off = 4 * (pp & 1);
-        af[i] = tr_frag(a + r0 * TBN + swz_a(r0, chunk) * 8 + off, a + r1 * TBN + swz_a(r1, chunk) * 8 + off);
+        af[i] = tr_frag(a + ra0 * TBN + swz_a(ra0, chunk) * 8 + off, a + ra1 * TBN + swz_a(ra1, chunk) * 8 + off);
       }
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         const int chunk = (wn * 80 + j * 16) / 8 + (pp >> 1), off = 4 * (pp & 1);
-        bf[j] = tr_frag(bq + r0 * TBK + swz_b(r0, chunk) * 8 + off, bq + r1 * TBK + swz_b(r1, chunk) * 8 + off);
+        bf[j] = tr_frag(bq + ra0 * TBK + swz_b(ra0, chunk) * 8 + off, bq + ra1 * TBK + swz_b(ra1, chunk) * 8 + off);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
   if (tid == 0) pr[q] = accb;
 }
 
-// out[c] += sum_r in[r*ld + c]; one workgroup per 64 columns, fixed summation order.
+// out[c] += sum_r in[r*ld + c]: workgroup (x, y) sums rows y, y + gridDim.y, ... of 64 columns and adds its partial
+// with one atomic per column (gridDim.y <= 32 partials per column).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int rows, int cols, int ld,
                                                      float* __restrict__ out) {
   __shared__ float red[4][64];
@@ -208,10 +209,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
   const int c = blockIdx.x * 64 + cx;
   float s = 0.f;
   if (c < cols)
-    for (int r = ry; r < rows; r += 4) s += in[(size_t)r * ld + c];
+    for (int r = blockIdx.y * 4 + ry; r < rows; r += 4 * gridDim.y) s += in[(size_t)r * ld + c];
   red[ry][cx] = s;
   __syncthreads();
-  if (ry == 0 && c < cols) out[c] += red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+  if (ry == 0 && c < cols) atomicAdd(out + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -474,8 +475,9 @@ int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float
   else
     hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)e, w2, alpha, g, ld_g, (float*)dpre, partial, n, L, N, q);
   NR_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_kernel, dim3((q + 63) / 64), dim3(256), 0, s, partial, nb, q, q + 1, dw2);
-  hipLaunchKernelGGL(colsum_kernel, dim3(1), dim3(256), 0, s, partial + q, nb, 1, q + 1, db2);
+  const int ysplit = nb >= 512 ? 32 : (nb >= 64 ? 8 : 1);
+  hipLaunchKernelGGL(colsum_kernel, dim3((q + 63) / 64, ysplit), dim3(256), 0, s, partial, nb, q, q + 1, dw2);
+  hipLaunchKernelGGL(colsum_kernel, dim3(1, ysplit), dim3(256), 0, s, partial + q, nb, 1, q + 1, db2);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
