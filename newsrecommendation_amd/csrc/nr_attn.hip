@@ -248,8 +248,10 @@ int nr_launch_attn(bool bwd, int dtype, const void* qkv, const float* mask, void
   NR_CHECK_ARG(n >= 1 && heads >= 1, "attention: empty problem");
   // L <= 32: one wave per (sequence, head) on the matrix cores; longer sequences: LDS/VALU kernels below.
   static const bool force_valu = getenv("NR_ATTN_VALU") != nullptr;
-  if (!force_valu && nr_attn_mfma_supported(L, d_head))
-    return nr_launch_attn_mfma(bwd, dtype, qkv, mask, y, dy, dqkv, n, L, heads, d_head, drop, stream);
+  if (!force_valu && nr_attn_mfma_supported(L, d_head)) {
+    const int rc = nr_launch_attn_mfma(bwd, dtype, qkv, mask, y, dy, dqkv, n, L, heads, d_head, drop, stream);
+    if (rc >= 0) return rc;   // -1: this shape / dtype has no MFMA kernel, use the LDS/VALU kernels below
+  }
   AttnArgs a;
   a.qkv = qkv; a.mask = mask; a.y = y; a.dy = dy; a.dqkv = dqkv;
   a.n = n; a.L = L; a.heads = heads; a.N = heads * d_head;

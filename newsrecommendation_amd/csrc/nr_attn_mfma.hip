@@ -740,11 +740,231 @@ __global__ __launch_bounds__(AW * 64) void bwd_kernel(AttnMArgs a) {
   }
 }
 
+
+// ---- 32 < L <= 64 (the clicked-history level): the 64 x 64 score matrix as 2 x 2 tiles of 32 x 32 -------------
+// Every matrix is two row-block images; queries are processed one 32-row block at a time against both key blocks.
+__device__ __forceinline__ int clampL(int L, int rb) { return min(32, max(0, L - 32 * rb)); }
+
+__global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  bf16_t* base = reinterpret_cast<bf16_t*>(smem) + (size_t)wid * 7 * IMG;
+  bf16_t *sQ = base, *sK = base + 2 * IMG, *sV = base + 4 * IMG, *sO = base + 6 * IMG;
+  float* sMask = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + (size_t)AW * 7 * IMG) + wid * 64;
+  const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
+  bf16_t* y = reinterpret_cast<bf16_t*>(a.y);
+  const int N = a.N, L = a.L, d = a.d, h2 = lane >> 5;
+  DropCfg nodrop;
+  nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
+  const int hgroups = (a.heads + AW - 1) / AW;
+  for (long sb = blockIdx.x; sb < a.n; sb += gridDim.x)
+    for (int hgi = 0; hgi < hgroups; ++hgi) {
+      const int hraw = hgi * AW + wid;
+      const bool active = hraw < a.heads;
+      const int head = active ? hraw : 0, Lw = active ? L : 0;
+      const size_t row0 = (size_t)sb * L;
+      const bf16_t* src = qkv + row0 * 3 * N + head * d;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        Slice t;
+        const int Lr = clampL(Lw, rb);
+        slice_load(t, src + (size_t)32 * rb * 3 * N, 3 * N, Lr, d, lane);
+        slice_put<false>(t, Lr, d, sQ + rb * IMG, lane, nodrop, 0, 0);
+        slice_load(t, src + (size_t)32 * rb * 3 * N + N, 3 * N, Lr, d, lane);
+        slice_put<false>(t, Lr, d, sK + rb * IMG, lane, nodrop, 0, 0);
+        slice_load(t, src + (size_t)32 * rb * 3 * N + 2 * N, 3 * N, Lr, d, lane);
+        slice_put<false>(t, Lr, d, sV + rb * IMG, lane, nodrop, 0, 0);
+      }
+      sMask[lane] = (lane < Lw) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
+      __syncthreads();
+#pragma unroll 1
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        mm_rr(s0, sK, sQ + qb * IMG, lane);         // keys 0..31   x queries of block qb
+        mm_rr(s1, sK + IMG, sQ + qb * IMG, lane);   // keys 32..63
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s0[r] *= a.scale; s1[r] *= a.scale;
+          if (rowof(r, h2) < L) m = fmaxf(m, s0[r]);
+          if (32 + rowof(r, h2) < L) m = fmaxf(m, s1[r]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = rowof(r, h2);
+          const float e0 = (j < L) ? __expf(s0[r] - m) * sMask[j] : 0.f;
+          const float e1 = (32 + j < L) ? __expf(s1[r] - m) * sMask[32 + j] : 0.f;
+          s0[r] = e0; s1[r] = e1;
+          sum += e0 + e1;
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / (sum + 1e-8f * __expf(-m));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] *= inv; s1[r] *= inv; }
+        f32x16 ctx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+        mm_xt(ctx, s0, sV, lane);
+        mm_xt(ctx, s1, sV + IMG, lane);
+        __syncthreads();
+        acc_to_img_t(ctx, 1.f, sO, lane);
+        __syncthreads();
+        const size_t r0 = row0 + 32 * qb;
+        img_t_to_global<true>(sO, y + r0 * N + head * d, N, clampL(Lw, qb), d, lane, a.drop, (uint32_t)(r0 * N + head * d), (uint32_t)N);
+      }
+      __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(AW * 64) void bwd64_kernel(AttnMArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  bf16_t* base = reinterpret_cast<bf16_t*>(smem) + (size_t)wid * 9 * IMG;
+  bf16_t *sQ = base, *sK = base + 2 * IMG, *sV = base + 4 * IMG, *sG = base + 6 * IMG, *sO = base + 8 * IMG;
+  float* sF = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + (size_t)AW * 9 * IMG) + wid * 256;
+  float *sMask = sF, *sM = sF + 64, *sInv = sF + 128, *sRd = sF + 192;
+  const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
+  const bf16_t* dy = reinterpret_cast<const bf16_t*>(a.dy);
+  bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.dqkv);
+  const int N = a.N, L = a.L, d = a.d, h2 = lane >> 5, li = lane & 31;
+  DropCfg nodrop;
+  nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
+  const int hgroups = (a.heads + AW - 1) / AW;
+  for (long sb = blockIdx.x; sb < a.n; sb += gridDim.x)
+    for (int hgi = 0; hgi < hgroups; ++hgi) {
+      const int hraw = hgi * AW + wid;
+      const bool active = hraw < a.heads;
+      const int head = active ? hraw : 0, Lw = active ? L : 0;
+      const size_t row0 = (size_t)sb * L;
+      const bf16_t* src = qkv + row0 * 3 * N + head * d;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        Slice t;
+        const int Lr = clampL(Lw, rb);
+        const size_t ro = (size_t)32 * rb;
+        slice_load(t, src + ro * 3 * N, 3 * N, Lr, d, lane);
+        slice_put<false>(t, Lr, d, sQ + rb * IMG, lane, nodrop, 0, 0);
+        slice_load(t, src + ro * 3 * N + N, 3 * N, Lr, d, lane);
+        slice_put<false>(t, Lr, d, sK + rb * IMG, lane, nodrop, 0, 0);
+        slice_load(t, src + ro * 3 * N + 2 * N, 3 * N, Lr, d, lane);
+        slice_put<false>(t, Lr, d, sV + rb * IMG, lane, nodrop, 0, 0);
+        slice_load(t, dy + (row0 + ro) * N + head * d, N, Lr, d, lane);
+        slice_put<true>(t, Lr, d, sG + rb * IMG, lane, a.drop, (uint32_t)((row0 + ro) * N + head * d), (uint32_t)N);
+      }
+      sMask[lane] = (lane < Lw) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
+      __syncthreads();
+      bf16_t* op = dqkv + row0 * 3 * N + head * d;
+      // phase A: per query block -> row statistics and dQ
+#pragma unroll 1
+      for (int qb = 0; qb < 2; ++qb) {
+        f32x16 s0, s1, p0, p1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; p0[r] = 0.f; p1[r] = 0.f; }
+        mm_rr(s0, sK, sQ + qb * IMG, lane);
+        mm_rr(s1, sK + IMG, sQ + qb * IMG, lane);
+        mm_rr(p0, sV, sG + qb * IMG, lane);         // dP^T
+        mm_rr(p1, sV + IMG, sG + qb * IMG, lane);
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s0[r] *= a.scale; s1[r] *= a.scale;
+          if (rowof(r, h2) < L) m = fmaxf(m, s0[r]);
+          if (32 + rowof(r, h2) < L) m = fmaxf(m, s1[r]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float sum = 0.f, rdu = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = rowof(r, h2);
+          const float e0 = (j < L) ? __expf(s0[r] - m) * sMask[j] : 0.f;
+          const float e1 = (32 + j < L) ? __expf(s1[r] - m) * sMask[32 + j] : 0.f;
+          s0[r] = e0; s1[r] = e1;
+          sum += e0 + e1;
+          rdu = fmaf(e0, p0[r], fmaf(e1, p1[r], rdu));
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        rdu += __shfl_xor(rdu, 32, 64);
+        const float inv = 1.f / (sum + 1e-8f * __expf(-m));
+        const float rd = rdu * inv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s0[r] = s0[r] * inv * (p0[r] - rd);       // dS^T
+          s1[r] = s1[r] * inv * (p1[r] - rd);
+        }
+        if (lane < 32) {
+          sM[32 * qb + lane] = m;
+          sInv[32 * qb + lane] = inv;
+          sRd[32 * qb + lane] = rd;
+        }
+        f32x16 dq;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+        mm_xt(dq, s0, sK, lane);
+        mm_xt(dq, s1, sK + IMG, lane);
+        __syncthreads();
+        acc_to_img_t(dq, a.scale, sO, lane);
+        __syncthreads();
+        img_t_to_global<false>(sO, op + (size_t)32 * qb * 3 * N, 3 * N, clampL(Lw, qb), d, lane, nodrop, 0, 0);
+      }
+      __syncthreads();
+      // phase B: per key block -> dK, dV (lane = key j, registers = query rows)
+#pragma unroll 1
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16 dk, dv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+        const float mj = sMask[32 * kb + li];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          f32x16 s, dp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+          mm_rr(s, sQ + qb * IMG, sK + kb * IMG, lane);
+          mm_rr(dp, sG + qb * IMG, sV + kb * IMG, lane);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = 32 * qb + rowof(r, h2);
+            const float pij = __expf(s[r] * a.scale - sM[i]) * mj * sInv[i];
+            s[r] = pij;
+            dp[r] = pij * (dp[r] - sRd[i]);
+          }
+          mm_xt(dk, dp, sQ + qb * IMG, lane);
+          mm_xt(dv, s, sG + qb * IMG, lane);
+        }
+        const int Lk = clampL(Lw, kb);
+        __syncthreads();
+        acc_to_img_t(dk, a.scale, sO, lane);
+        __syncthreads();
+        img_t_to_global<false>(sO, op + (size_t)32 * kb * 3 * N + N, 3 * N, Lk, d, lane, nodrop, 0, 0);
+        __syncthreads();
+        acc_to_img_t(dv, 1.f, sO, lane);
+        __syncthreads();
+        img_t_to_global<false>(sO, op + (size_t)32 * kb * 3 * N + 2 * N, 3 * N, Lk, d, lane, nodrop, 0, 0);
+      }
+      __syncthreads();
+    }
+}
+
 int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   long blocks = a.n;   // one workgroup per sequence (grid-stride beyond the cap), all heads inside
-  const size_t smem = bwd ? AW * (4 * IMG * sizeof(bf16_t) + 128 * sizeof(float)) : AW * (3 * IMG * sizeof(bf16_t) + 32 * sizeof(float));
   const long cap = 256L * 4 * 4;
   if (blocks > cap) blocks = cap;
+  if (a.L > 32) {
+    const size_t smem64 = bwd ? AW * (9 * IMG * sizeof(bf16_t) + 256 * sizeof(float)) : AW * (7 * IMG * sizeof(bf16_t) + 64 * sizeof(float));
+    if (bwd) {
+      NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bwd64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64));
+      hipLaunchKernelGGL(bwd64_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+    } else {
+      hipLaunchKernelGGL(fwd64_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+    }
+    NR_CHECK_LAUNCH();
+    return NR_OK;
+  }
+  const size_t smem = bwd ? AW * (4 * IMG * sizeof(bf16_t) + 128 * sizeof(float)) : AW * (3 * IMG * sizeof(bf16_t) + 32 * sizeof(float));
   if (bwd) hipLaunchKernelGGL(bwd_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
   else hipLaunchKernelGGL(fwd_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
   NR_CHECK_LAUNCH();
@@ -775,11 +995,12 @@ int launch_t(bool bwd, const AttnMArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-bool nr_attn_mfma_supported(int L, int d_head) { return L >= 1 && L <= 32 && d_head >= 1 && d_head <= 32; }
+// L <= 32: every dtype; 32 < L <= 64: the bf16 fast path only (vector-aligned slices); else the LDS/VALU kernels
+bool nr_attn_mfma_supported(int L, int d_head) { return L >= 1 && L <= 64 && d_head >= 1 && d_head <= 32; }
 
 int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask, void* y, const void* dy, void* dqkv, int n,
                         int L, int heads, int d_head, const DropCfg& drop, hipStream_t stream) {
-  NR_CHECK_ARG(nr_attn_mfma_supported(L, d_head), "attn_mfma: L=%d d_head=%d unsupported", L, d_head);
+  if (!nr_attn_mfma_supported(L, d_head)) return -1;
   AttnMArgs a;
   a.qkv = qkv; a.mask = mask; a.y = y; a.dy = dy; a.dqkv = dqkv;
   a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;
@@ -787,8 +1008,10 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   a.drop = drop;
   const uintptr_t al = dtype == NR_BF16 ? 7 : 15;
   a.vec = (d_head % 4 == 0) && (((uintptr_t)qkv | (uintptr_t)y | (uintptr_t)dy | (uintptr_t)dqkv) & al) == 0;
-  NrProfScope ps(stream, "attn_mfma_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? "bwd" : "fwd", dtype == NR_BF16 ? "bf16" : "f32", n, L, heads, d_head);
   static const bool old_path = getenv("NR_ATTN_OLD") != nullptr;
-  if (dtype == NR_BF16 && a.vec && !old_path) return b16::launch(bwd, a, stream);
+  const bool fast = dtype == NR_BF16 && a.vec && !old_path;
+  if (L > 32 && !fast) return -1;   // caller falls back to the LDS/VALU kernels
+  NrProfScope ps(stream, "attn_mfma_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? "bwd" : "fwd", dtype == NR_BF16 ? "bf16" : "f32", n, L, heads, d_head);
+  if (fast) return b16::launch(bwd, a, stream);
   return dtype == NR_BF16 ? launch_t<bf16_t>(bwd, a, stream) : launch_t<float>(bwd, a, stream);
 }

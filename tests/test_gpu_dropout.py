@@ -21,7 +21,7 @@ def _nrms_masks(cfg, B, seed_in, seed_out):
 
 
 @pytest.mark.parametrize("tag,dt,tol,gtol", [("nrms_tiny_pad", "fp32", 1e-4, 2e-4), ("nrms_mind_pad", "fp32", 1e-4, 2e-4),
-                                             ("nrms_mind_pad", "bf16", 4e-2, 8e-2)])
+                                             ("nrms_mind_pad", "bf16", 4e-2, 1e-1)])
 def test_nrms_train_mode_matches_oracle_with_same_masks(tag, dt, tol, gtol):
     m, z, cfg, sd = build_model(tag, dt, train=True)
     hist, mask, cand, label = batch_of(z)
