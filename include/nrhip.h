@@ -104,7 +104,11 @@ typedef struct {
   int ld_rows;
 } nr_mhsa_desc;
 
-/* qkv: [n*L, 3N] dtype (saved for backward); y: [n*L, N] dtype. */
+/* qkv: [n*L, 3N] dtype (saved for backward); y: [n*L, N] dtype.
+ * Title-level bf16 gather sources (L <= 32, 3*d_head <= 64, 288 < d_model <= 320) run as ONE fused kernel that keeps
+ * Q|K|V on chip; nr_mhsa_fwd_fused(d) returns 1 for such a descriptor, and then qkv may be NULL (inference: the
+ * projections are never written to HBM).  On every other path qkv is required.                              */
+int nr_mhsa_fwd_fused(const nr_mhsa_desc* d);
 int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream);
 /* dy [n*L, N] dtype.  dqkv: workspace [n*L, 3N] dtype.  w_qkv_t: [Kp, ldwt] dtype = w_qkv^T
  * (nr_cast_pad transpose=1; Kp = d_model rounded up to a chunk; needed only if dx/dtable).

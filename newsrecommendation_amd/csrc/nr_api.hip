@@ -14,6 +14,10 @@ int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float
                             int ld_g, void* dpre, float* partial, float* dw2, float* db2, int n, int L, int N, int q,
                             hipStream_t s);
 int nr_launch_cast_rows(int dtype, const float* src, int ld_src, void* dst, int ld_dst, int rows, int cols, hipStream_t s);
+bool nr_mhsa_fused_shape_ok(int L, int heads, int d_head, int d_model, int ldt, int ldw);
+int nr_launch_mhsa_fused_fwd(const void* table, int ldt, const int32_t* ids, const void* w, int ldw, const float* bias,
+                             const float* mask, void* qkv, void* xrows, int ldxr, void* y, int n, int L, int heads, int d_head,
+                             int d_model, const DropCfg& drop_in, const DropCfg& drop_out, hipStream_t stream);
 
 #include <map>
 #include <mutex>
@@ -181,15 +185,31 @@ int nr_gemm_tn(int dtype, const void* dC, int ldc, const void* A, int lda, float
 }
 
 // ---------------------------------------------------------------------------------------- MHSA
+int nr_mhsa_fwd_fused(const nr_mhsa_desc* d) {
+  if (d == nullptr) return 0;
+  return d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER && (((uintptr_t)d->x | (uintptr_t)d->w_qkv) & 15) == 0 &&
+                 nr_mhsa_fused_shape_ok(d->L, d->heads, d->d_head, d->d_model, d->ldx, d->ldw)
+             ? 1
+             : 0;
+}
+
 int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   int rc = mhsa_check(d);
   if (rc) return rc;
   if (d->n == 0) return NR_OK;
-  NR_CHECK_ARG(qkv && y, "mhsa_fwd: null output");
+  NR_CHECK_ARG(y != nullptr, "mhsa_fwd: null output");
   hipStream_t s = (hipStream_t)stream;
   const int N = d->heads * d->d_head, M = d->n * d->L, Kp = round_up(d->d_model, nr_chunk(d->dtype));
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
+  if (d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER) {
+    // title level: one fused kernel (gather, dropout, projection, attention, dropout); -1 = shape not covered
+    rc = nr_launch_mhsa_fused_fwd(d->x, d->ldx, d->ids, d->w_qkv, d->ldw, d->b_qkv, d->mask, qkv, d->x_rows, d->ld_rows, y, d->n, d->L,
+                                  d->heads, d->d_head, d->d_model, nr_make_drop(d->p_in, d->seed_in),
+                                  nr_make_drop(d->p_out, d->seed_out), s);
+    if (rc >= 0) return rc;
+  }
+  NR_CHECK_ARG(qkv != nullptr, "mhsa_fwd: the unfused path needs the qkv buffer (see nr_mhsa_fwd_fused)");
   EpiArgs ep = store_epi(qkv, 3 * N, d->dtype, d->b_qkv, 0);
   if (d->x_rows != nullptr && d->src_kind == NR_SRC_GATHER) {
     // gather + dropout once into x_rows (kept for the backward), then a plain dense projection GEMM

@@ -949,6 +949,191 @@ __global__ __launch_bounds__(AW * 64) void bwd64_kernel(AttnMArgs a) {
     }
 }
 
+
+// ==========================================================================================
+// Fused forward of the title level (K1 + K2 + K3): embedding gather -> dropout -> Q|K|V projection ->
+// per-head attention -> dropout, one WAVE per title, the title's [32 x 320] input rows held in registers as
+// MFMA operands for the whole kernel.  Per head the workgroup (4 waves = 4 titles) stages the head's
+// [Q_h | K_h | V_h] weight rows (64 x 320, from L2) in LDS, double buffered; each wave then
+//   1. projects its title: 80 x v_mfma_f32_16x16x32_bf16 with the weights as the MFMA row operand, so a lane
+//      owns 4 consecutive output columns of one token (bias added in registers),
+//   2. drops the 60 columns as 8-byte writes into its three private swizzled 32 x 32 images (and, when the
+//      backward will need them, into the token-major Q|K|V buffer),
+//   3. runs the 32 x 32 attention tile on 32x32x16 MFMA exactly as fwd_kernel above and stores y.
+// Q|K|V never make a round trip through HBM on this path; with qkv == nullptr (inference) they are not
+// written at all.
+// ==========================================================================================
+struct FusedArgs {
+  const bf16_t* table; int ldt;
+  const int32_t* ids;
+  const bf16_t* w; int ldw;
+  const float* bias;
+  const float* mask;
+  bf16_t* qkv;
+  bf16_t* xrows; int ldxr;
+  bf16_t* y;
+  int n, L, heads, d, N, d_model;
+  float scale;
+  DropCfg drop_in, drop_out;
+};
+
+template <int KS>
+__global__ __launch_bounds__(AW * 64) void fused_fwd_kernel(FusedArgs a) {
+  constexpr int WS = KS * 32 + 8;                 // LDS row stride of the weight chunk (elements)
+  constexpr int WCH = KS * 4;                     // 16-byte chunks per weight row
+  constexpr int NWL = 64 * WCH / (AW * 64);       // weight chunks staged per thread per head
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* sW = reinterpret_cast<bf16_t*>(smem);                   // [2][64][WS]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  bf16_t* img = sW + 2 * 64 * WS + (size_t)wid * 4 * IMG;
+  bf16_t *sQ = img, *sK = img + IMG, *sV = img + 2 * IMG, *sO = img + 3 * IMG;
+  float* sMask = reinterpret_cast<float*>(sW + 2 * 64 * WS + (size_t)AW * 4 * IMG) + wid * 32;
+  const int N = a.N, L = a.L, d = a.d, h2 = lane >> 5;
+  const int fr = lane & 15, g = lane >> 4;
+  const long title = (long)blockIdx.x * AW + wid;
+  const bool active = title < a.n;
+  const size_t row0 = (size_t)(active ? title : 0) * L;
+
+  // zero the private images once: pad columns (>= d) are never written again
+  for (int e = lane; e < 4 * IMG / 8; e += 64) reinterpret_cast<uint4*>(img)[e] = make_uint4(0, 0, 0, 0);
+  if (lane < 32) sMask[lane] = (active && lane < L) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
+
+  // the title's input rows as MFMA operands: xf[i][s] = X[16 i + fr][32 s + 8 g .. + 8)
+  bf16x8 xf[2][KS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 16 * i + fr;
+    const bool valid = active && row < L;
+    const int id = valid ? a.ids[row0 + row] : 0;
+    const bf16_t* src = a.table + (size_t)id * a.ldt + 8 * g;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8 v = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+      if (valid) v = *reinterpret_cast<const bf16x8*>(src + 32 * s);
+      const int col = 32 * s + 8 * g;
+      if (a.drop_in.thresh && valid) {
+        const uint32_t e0 = (uint32_t)(row0 + row) * (uint32_t)a.d_model + (uint32_t)col;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (col + e < a.d_model) v[e] = nr_keep(a.drop_in.key, e0 + e, a.drop_in.thresh) ? (bf16_t)((float)v[e] * a.drop_in.scale) : (bf16_t)0.f;
+      }
+      xf[i][s] = v;
+      if (a.xrows != nullptr && valid && col < a.ldxr) *reinterpret_cast<bf16x8*>(a.xrows + (row0 + row) * a.ldxr + col) = v;
+    }
+  }
+
+  // weight chunk of head h: rows [Q_h (d) | K_h (d) | V_h (d) | zeros], staged global -> registers -> LDS
+  uint4 wr[NWL];
+  auto wload = [&](int h) {
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int c = tid + i * AW * 64, r = c / WCH, ch = c - r * WCH;
+      uint4 z = make_uint4(0, 0, 0, 0);
+      if (r < 3 * d) {
+        const int which = r / d, rr = r - which * d;
+        z = *reinterpret_cast<const uint4*>(a.w + (size_t)(which * N + h * d + rr) * a.ldw + ch * 8);
+      }
+      wr[i] = z;
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NWL; ++i) {
+      const int c = tid + i * AW * 64, r = c / WCH, ch = c - r * WCH;
+      *reinterpret_cast<uint4*>(sW + (size_t)buf * 64 * WS + r * WS + ch * 8) = wr[i];
+    }
+  };
+  wload(0);
+  wstore(0);
+  __syncthreads();
+
+  for (int h = 0; h < a.heads; ++h) {
+    const int cur = h & 1;
+    if (h + 1 < a.heads) wload(h + 1);
+    // ---- projection: C[token][col] for 32 tokens x 64 columns; a lane owns cols 16 j + 4 g .. + 4 of token 16 i + fr
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bf16_t* wc = sW + (size_t)cur * 64 * WS;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8 wf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(wc + (16 * j + fr) * WS + 32 * s + 8 * g);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i][s], acc[i][j], 0, 0, 0);
+    }
+    // ---- bias, bf16, images (+ token-major Q|K|V for the backward)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 16 * j + 4 * g;                 // first of the lane's 4 chunk columns
+      if (c < 3 * d) {
+        const int which = c / d, cc = c - which * d;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + which * N + h * d + cc);
+        bf16_t* im = which == 0 ? sQ : (which == 1 ? sK : sV);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = 16 * i + fr;
+          const f32x4 v = acc[i][j] + bv;
+          const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          *reinterpret_cast<bf16x4*>(im + ioff(row, cc)) = o;
+          if (a.qkv != nullptr && active && row < L)
+            *reinterpret_cast<bf16x4*>(a.qkv + (row0 + row) * 3 * N + which * N + h * d + cc) = o;
+        }
+      }
+    }
+    if (h + 1 < a.heads) wstore(cur ^ 1);
+    __syncthreads();
+    // ---- attention tile (as fwd_kernel)
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    mm_rr(st, sK, sQ, lane);
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] *= a.scale;
+      if (rowof(r, h2) < L) m = fmaxf(m, st[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jj = rowof(r, h2);
+      const float e = (jj < L) ? __expf(st[r] - m) * sMask[jj] : 0.f;
+      st[r] = e;
+      sum += e;
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / (sum + 1e-8f * __expf(-m));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] *= inv;
+    f32x16 ctx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+    mm_xt(ctx, st, sV, lane);
+    acc_to_img_t(ctx, 1.f, sO, lane);
+    __syncthreads();
+    img_t_to_global<true>(sO, a.y + row0 * N + h * d, N, active ? L : 0, d, lane, a.drop_out, (uint32_t)(row0 * N + h * d), (uint32_t)N);
+    // next head's barrier (after its projection) orders these image reads before the next image writes:
+    // the projection phase touches only registers and the weight buffer
+  }
+}
+
+int launch_fused_fwd(const FusedArgs& a, hipStream_t stream) {
+  constexpr int KS = 10;
+  constexpr size_t smem = (size_t)2 * 64 * (KS * 32 + 8) * sizeof(bf16_t) + (size_t)AW * 4 * IMG * sizeof(bf16_t) + AW * 32 * sizeof(float);
+  auto k = fused_fwd_kernel<KS>;
+  NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(k, dim3((a.n + AW - 1) / AW), dim3(AW * 64), smem, stream, a);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
 int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   long blocks = a.n;   // one workgroup per sequence (grid-stride beyond the cap), all heads inside
   const long cap = 256L * 4 * 4;
@@ -1014,4 +1199,30 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   NrProfScope ps(stream, "attn_mfma_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? "bwd" : "fwd", dtype == NR_BF16 ? "bf16" : "f32", n, L, heads, d_head);
   if (fast) return b16::launch(bwd, a, stream);
   return dtype == NR_BF16 ? launch_t<bf16_t>(bwd, a, stream) : launch_t<float>(bwd, a, stream);
+}
+
+
+// Fused title-level forward (gather + dropout + Q|K|V projection + attention + dropout), bf16 only.
+// Returns -1 when the shape is outside what the fused kernel covers (the caller then runs the unfused path).
+bool nr_mhsa_fused_shape_ok(int L, int heads, int d_head, int d_model, int ldt, int ldw) {
+  static const bool off = getenv("NR_NO_FUSED_FWD") != nullptr;
+  if (off) return false;
+  return L >= 1 && L <= 32 && d_head % 4 == 0 && 3 * d_head <= 64 && d_model <= 320 && d_model > 288 && ldt >= 320 && ldw >= 320 &&
+         (heads * d_head) % 4 == 0;
+}
+
+int nr_launch_mhsa_fused_fwd(const void* table, int ldt, const int32_t* ids, const void* w, int ldw, const float* bias,
+                             const float* mask, void* qkv, void* xrows, int ldxr, void* y, int n, int L, int heads, int d_head,
+                             int d_model, const DropCfg& drop_in, const DropCfg& drop_out, hipStream_t stream) {
+  if (!nr_mhsa_fused_shape_ok(L, heads, d_head, d_model, ldt, ldw)) return -1;
+  if ((heads * d_head) % 4 != 0 || (((uintptr_t)table | (uintptr_t)w | (uintptr_t)y | (uintptr_t)qkv | (uintptr_t)xrows) & 15) != 0) return -1;
+  if (xrows != nullptr && (ldxr % 8 != 0)) return -1;
+  b16::FusedArgs a;
+  a.table = (const bf16_t*)table; a.ldt = ldt; a.ids = ids; a.w = (const bf16_t*)w; a.ldw = ldw; a.bias = bias; a.mask = mask;
+  a.qkv = (bf16_t*)qkv; a.xrows = (bf16_t*)xrows; a.ldxr = ldxr; a.y = (bf16_t*)y;
+  a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head; a.d_model = d_model;
+  a.scale = 1.0f / sqrtf((float)d_head);
+  a.drop_in = drop_in; a.drop_out = drop_out;
+  NrProfScope ps(stream, "mhsa_fused_fwd[bf16,n=%d,L=%d,h=%d,d=%d,D=%d,save_qkv=%d]", n, L, heads, d_head, d_model, qkv != nullptr);
+  return b16::launch_fused_fwd(a, stream);
 }

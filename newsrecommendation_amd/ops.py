@@ -122,9 +122,9 @@ class MHSAFunction(Function):
         b_p = torch.cat([bq, bk, bv]).detach().float().contiguous()
         mask_c = mask.contiguous().float() if mask is not None else None
         dev = wq.device
-        qkv = torch.empty(n * L, 3 * N, dtype=torch_dtype(code), device=dev)
         y = torch.empty(n, L, N, dtype=torch_dtype(code), device=dev)
         # training with a gather source: keep the gathered + dropped-out rows for the weight-gradient GEMM
+        need_bwd = any(ctx.needs_input_grad[:7])
         keep_rows = gather and any(ctx.needs_input_grad[1:7])
         Kp = round_up(d_model, ch)
         x_rows = torch.empty(n * L, Kp, dtype=torch_dtype(code), device=dev) if keep_rows else None
@@ -133,6 +133,9 @@ class MHSAFunction(Function):
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
                           x_rows=ptr(x_rows), ld_rows=Kp)
+        # the fused title-level kernel keeps Q|K|V on chip: without a backward they are never written to HBM
+        fused = bool(_lib.lib().nr_mhsa_fwd_fused(C.byref(d)))
+        qkv = None if (fused and not need_bwd) else torch.empty(n * L, 3 * N, dtype=torch_dtype(code), device=dev)
         check(_lib.lib().nr_mhsa_fwd(C.byref(d), ptr(qkv), ptr(y), _stream()), "nr_mhsa_fwd")
         ctx.cfg, ctx.dims = cfg, (n, L, N, d_model, heads, d_head, ldx, gather)
         ctx.save_for_backward(src, ids, mask_c, w_p, b_p, wcat, qkv, x_rows)
