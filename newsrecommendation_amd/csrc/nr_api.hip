@@ -202,10 +202,12 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   const int N = d->heads * d->d_head, M = d->n * d->L, Kp = round_up(d->d_model, nr_chunk(d->dtype));
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
-  if (d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER) {
-    // title level: one fused kernel (gather, dropout, projection, attention, dropout); -1 = shape not covered
-    rc = nr_launch_mhsa_fused_fwd(d->x, d->ldx, d->ids, d->w_qkv, d->ldw, d->b_qkv, d->mask, qkv, d->x_rows, d->ld_rows, y, d->n, d->L,
-                                  d->heads, d->d_head, d->d_model, nr_make_drop(d->p_in, d->seed_in),
+  if (qkv == nullptr && d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER) {
+    // Inference (no backward -> the caller passes no qkv buffer): one fused kernel, gather + projection + attention with
+    // Q|K|V kept on chip.  Measured on MI355X it ties the unfused chain in time (2.8 ms per 28 160 titles) and saves
+    // the 2 GB Q|K|V round trip; with a backward pending the unfused chain is used because it has to write Q|K|V anyway.
+    rc = nr_launch_mhsa_fused_fwd(d->x, d->ldx, d->ids, d->w_qkv, d->ldw, d->b_qkv, d->mask, nullptr, d->x_rows, d->ld_rows, y, d->n,
+                                  d->L, d->heads, d->d_head, d->d_model, nr_make_drop(d->p_in, d->seed_in),
                                   nr_make_drop(d->p_out, d->seed_out), s);
     if (rc >= 0) return rc;
   }
