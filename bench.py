@@ -61,6 +61,25 @@ def synth_batches(args, B, V, n_batches, seed, device):
     return out
 
 
+def synth_batches_naml(args, B, n_news, n_batches, seed, device):
+    """NAML inputs: [news id, category id (<=17), subcategory id (<=264)] per slot."""
+    g = torch.Generator().manual_seed(seed)
+    H, C = args.user_log_length, 1 + args.npratio
+    out = []
+    for _ in range(n_batches):
+        def ids(shape):
+            return torch.stack([torch.randint(1, n_news + 1, shape, generator=g, dtype=torch.int32),
+                                torch.randint(0, 18, shape, generator=g, dtype=torch.int32),
+                                torch.randint(0, 265, shape, generator=g, dtype=torch.int32)], dim=-1)
+        hist, cand = ids((B, H)), ids((B, C))
+        hl = torch.randint(0, H + 1, (B,), generator=g)
+        mask = (torch.arange(H)[None, :] >= (H - hl)[:, None]).float()
+        hist[mask == 0] = 0
+        label = torch.randint(0, C, (B,), generator=g, dtype=torch.int64)
+        out.append(tuple(x.to(device) for x in (hist, mask, cand, label)))
+    return out
+
+
 def gemm_flops(label):
     m = re.search(r"M=(\d+),N=(\d+),K=(\d+)", label)
     M, N, K = (int(x) for x in m.groups())
@@ -76,6 +95,25 @@ def attn_bytes(label, esz):
     return rows * (3 * N + N + 3 * N) * esz        # read Q|K|V + dy, write dQ|dK|dV
 
 
+def pmc_traffic(label):
+    """HBM bytes per launch of the kernel behind `label`, from the committed rocprofv3 PMC passes of this command
+    (profiles/*_hbm_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled as
+    MI355X_MICROARCH.md prescribes for 16-byte coalesced reads on gfx950).  None when no matching entry exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")))
+    if not files:
+        return None
+    key = {"gemm_nt[": "gemm_nt_kernelIDF16bLi0ELi0", "gemm_nt_dma": "gemm_nt_dma_kernel", "gemm_tn2": "tn2::gemm_tn2_kernel",
+           "attn_mfma_bwd": "b16::bwd_kernel", "attn_mfma_fwd": "b16::fwd_kernel", "gemm_nt_wide": "gemm_nt_wide_kernel"}
+    want = next((v for k, v in key.items() if label.startswith(k)), None)
+    if want is None:
+        return None
+    for k in json.load(open(files[-1]))["kernels"]:
+        if want in k["kernel"]:
+            return round((k["fetch_GB_x2_gfx950_16B_correction"] + k["write_GB"]) * 1e9)
+    return None
+
+
 def roofline_of(prof, dtype):
     """Pick the kernel with the largest total time in the timed region and price it."""
     if not prof:
@@ -88,12 +126,14 @@ def roofline_of(prof, dtype):
         peak = PEAK_MFMA_BF16 if "bf16" in label else PEAK_MFMA_F32
         ach = fl / avg_s / 1e12
         return {"kernel": label, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "avg_ms": round(ms / cnt, 4), "launches": cnt}
+                "frac": round(ach / peak, 4), "traffic": pmc_traffic(label), "avg_ms": round(ms / cnt, 4), "launches": cnt,
+                "algorithmic_flops": fl}
     if label.startswith("attn"):
         by = attn_bytes(label, esz)
         ach = by / avg_s / 1e9
         return {"kernel": label, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM, "unit": "GB/s",
-                "frac": round(ach / PEAK_HBM, 4), "traffic": None, "avg_ms": round(ms / cnt, 4), "launches": cnt}
+                "frac": round(ach / PEAK_HBM, 4), "traffic": pmc_traffic(label), "avg_ms": round(ms / cnt, 4), "launches": cnt,
+                "algorithmic_bytes": by}
     return {"kernel": label, "bound": "hbm", "achieved": None, "peak": PEAK_HBM, "unit": "GB/s", "frac": None,
             "traffic": None, "avg_ms": round(ms / cnt, 4), "launches": cnt}
 
@@ -140,6 +180,9 @@ def main():
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--vocab", type=int, default=30000)
+    ap.add_argument("--model", default="NRMS", choices=["NRMS", "NAML"],
+                    help="NRMS = the headline config; NAML = BASELINE config[2] (multi-view, frozen [N+1, T*D] title table)")
+    ap.add_argument("--naml-news", type=int, default=65000)
     ap.add_argument("--freeze-embedding", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
@@ -158,21 +201,31 @@ def main():
         dist.init_process_group("nccl", device_id=device)   # 'nccl' == RCCL on ROCm (src/main.py:31)
 
     from newsrecommendation_amd import _lib
-    from newsrecommendation_amd.model import NRMS
+    from newsrecommendation_amd.model import NAML, NRMS
 
     args = make_args(a.dtype)
     args.freeze_embedding = bool(a.freeze_embedding)
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(1)
-    table = torch.randn(a.vocab, args.word_embedding_dim, generator=g) * 0.4
-    table[0] = 0
-    model = NRMS.Model(args, table.numpy()).to(device)
+    if a.model == "NRMS":
+        table = torch.randn(a.vocab, args.word_embedding_dim, generator=g) * 0.4
+        table[0] = 0
+        model = NRMS.Model(args, table.numpy()).to(device)
+    else:
+        args.use_category = args.use_subcategory = True
+        args.freeze_embedding = True                      # src/demo.sh:12
+        table = torch.randn(a.naml_news + 1, args.num_words_title * args.word_embedding_dim, generator=g) * 0.4
+        table[0] = 0
+        model = NAML.Model(args, table.numpy(), 17, 264).to(device)
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)      # src/main.py:76 (defaults)
     net = model
     if dist_on:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])   # src/main.py:82
-    batches = synth_batches(args, a.batch, a.vocab, 4, 100 + rank, device)
+    if a.model == "NRMS":
+        batches = synth_batches(args, a.batch, a.vocab, 4, 100 + rank, device)
+    else:
+        batches = synth_batches_naml(args, a.batch, a.naml_news, 4, 100 + rank, device)
 
     def step(i):
         hist, mask, cand, label = batches[i % len(batches)]
@@ -210,11 +263,11 @@ def main():
 
     if rank == 0:
         total = a.batch * world * a.steps
-        out = {"metric": "train impressions/sec @ batch 512, NRMS", "value": round(total / dt, 1), "unit": "impressions/s",
+        out = {"metric": "train impressions/sec @ batch 512, " + a.model, "value": round(total / dt, 1), "unit": "impressions/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": "NRMS train step (fwd+bwd+Adam), MIND-small shapes: title_len=30, history=50, "
-                                      "npratio=4, 300-d word table",
+               "config": {"workload": a.model + " train step (fwd+bwd+Adam), MIND-small shapes: title_len=30, history=50, "
+                                      "npratio=4, 300-d " + ("word table" if a.model == "NRMS" else "per-news title rows, 3 views"),
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "vocab_rows": a.vocab,
                           "dropout": args.drop_rate, "freeze_embedding": args.freeze_embedding,
                           "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)}}
@@ -224,7 +277,7 @@ def main():
             out["kernel_ms_per_step"] = {k: round(ms / a.steps, 4) for k, (c, ms) in
                                          sorted(prof.items(), key=lambda kv: -kv[1][1])[:12]}
             out["kernel_ms_per_step"]["_all_libnrhip_kernels"] = round(tot / a.steps, 4)
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.model == "NRMS":
             out["cpu_baseline"] = cpu_baseline(args, a.vocab, 7)
         print(json.dumps(out))
     if dist_on:
