@@ -928,7 +928,7 @@ __device__ __forceinline__ int swzP(int row) { return (0x78 >> (2 * ((row >> 2) 
 
 constexpr int DBM = 256;   // rows per workgroup of the DMA kernel: 8 waves x 32 rows, every wave spans all N columns
 
-template <int EPI, int NT16>
+template <int EPI, int NT16, bool PK>
 __global__ __launch_bounds__(WTHR) void gemm_nt_dma_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                            int ldb, int M, int Ntot, int K, EpiArgs ep, int nchunks) {
   constexpr int WBN = NT16 * 16;
@@ -1022,12 +1022,72 @@ __global__ __launch_bounds__(WTHR) void gemm_nt_dma_kernel(const bf16_t* __restr
       if (wn * HN + j < NT16) {
         const bf16x8 bf = *reinterpret_cast<const bf16x8*>(st + offB + j * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+          // PK: weights on the MFMA row side -> a lane owns 4 consecutive output columns of one row
+          if (PK) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
+        }
       }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (PK) {
+    // packed bf16 epilogue: 128 rows at a time through a bf16 LDS image (8-byte writes), 16-byte row stores
+    bf16_t* sCb = reinterpret_cast<bf16_t*>(smem);
+    constexpr int SCB = WBN + 8;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass) __syncthreads();
+      if ((wm >> 1) == pass) {
+#pragma unroll
+        for (int j = 0; j < HN; ++j) {
+          const int jt = wn * HN + j;
+          if (jt < NT16) {
+            const int nl = jt * 16 + 4 * (lane >> 4);
+            f32x4 bvec = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if ((EPI == EPI_STORE || EPI == EPI_STORE_TANH) && ep.bias != nullptr) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (nl + r < N) bvec[r] = ep.bias[nbase + nl + r];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int ml = (wm & 1) * 64 + i * 16 + (lane & 15), m = m0 + pass * 128 + ml;
+              f32x4 v = acc[i][j] + bvec;
+              if (EPI == EPI_STORE_TANH) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+              }
+              if (EPI == EPI_POOLBWD && m < M) {
+                const float rs = ep.rowscale[m];
+                const float* grow = ep.G + (size_t)(m / ep.L) * ep.ldg + nbase;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  if (nl + r < N) v[r] += rs * grow[nl + r];
+              }
+              const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+              *reinterpret_cast<bf16x4*>(sCb + ml * SCB + nl) = o;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      for (int u = tid; u < 128 * (WBN / 8); u += WTHR) {
+        const int row = u / (WBN / 8), c0 = (u % (WBN / 8)) * 8;
+        const int m = m0 + pass * 128 + row;
+        if (m < M && c0 < N) {
+          bf16_t* dst = (bf16_t*)ep.C + (size_t)m * ep.ldc + nbase + c0;
+          if (c0 + 8 <= N && (ep.ldc % 8) == 0 && (nbase % 8) == 0) {
+            *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(sCb + row * SCB + c0);
+          } else {
+            for (int e = 0; e < 8 && c0 + e < N; ++e) dst[e] = sCb[row * SCB + c0 + e];
+          }
+        }
+      }
+    }
+    return;
+  }
   // epilogue: 32 rows at a time through the fp32 LDS tile (pass p = rows 32p..32p+31 = wave row wm = p>>1, tiles 2(p&1), +1)
 #pragma unroll 1
   for (int pass = 0; pass < 8; ++pass) {
@@ -1061,12 +1121,13 @@ __global__ __launch_bounds__(WTHR) void gemm_nt_dma_kernel(const bf16_t* __restr
   }
 }
 
-template <int EPI, int NT16>
-int launch_nt_dma_t(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
+template <int EPI, int NT16, bool PK>
+int launch_nt_dma_p(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
   constexpr int NP = DBM / 16 + NT16, STAGE = NP * 1024, NS = (4 * STAGE <= 150 * 1024) ? 4 : 3;
   constexpr size_t ring = (size_t)NS * STAGE, epi = (size_t)32 * (NT16 * 16 + 4) * sizeof(float);
-  constexpr size_t smem = ring > epi ? ring : epi;
-  auto kern = gemm_nt_dma_kernel<EPI, NT16>;
+  constexpr size_t epk = (size_t)128 * (NT16 * 16 + 8) * sizeof(bf16_t);
+  constexpr size_t smem0 = ring > epi ? ring : epi, smem = smem0 > epk ? smem0 : epk;
+  auto kern = gemm_nt_dma_kernel<EPI, NT16, PK>;
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   const int tilesM = (M + DBM - 1) / DBM, nchunks = (N + NT16 * 16 - 1) / (NT16 * 16);
   const int grid = ((tilesM + 7) / 8) * 8 * nchunks;
@@ -1074,6 +1135,12 @@ int launch_nt_dma_t(const RowSrc& A, const void* B, int ldb, int M, int N, int K
                      nchunks);
   NR_CHECK_LAUNCH();
   return NR_OK;
+}
+
+template <int EPI, int NT16>
+int launch_nt_dma_t(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
+  if (EPI != EPI_SCATTER && ep.out_dtype == NR_BF16) return launch_nt_dma_p<EPI, NT16, true>(A, B, ldb, M, N, K, ep, stream);
+  return launch_nt_dma_p<EPI, NT16, false>(A, B, ldb, M, N, K, ep, stream);
 }
 
 template <int NT16>
@@ -1185,14 +1252,16 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
   if (epi != EPI_SCATTER) NR_CHECK_ARG(ep.ldc % 4 == 0 && ((uintptr_t)ep.C & 15) == 0, "gemm_nt: output ld %d / alignment", ep.ldc);
   if (epi == EPI_STORE && ep.act_tanh) epi = EPI_STORE_TANH;
   // Kernel choice (bf16, dense A), from per-shape measurements on MI355X (tools/gemm_probe.py):
-  //   K >= 512            : LDS-DMA ring kernel (long k loop: the prefetch ring pays, A read once)
+  //   K >= 256            : LDS-DMA ring kernel, 256-row tiles x column chunks of 208 / 320 (QKV projection K=304:
+  //                         1.42 ms vs 1.92 ms tiled; att_fc1 K=400; dX K=1200), packed bf16 epilogue
   //   N <= 208, small K   : "wide" kernel, all N columns per workgroup (A read once)
-  //   otherwise           : 128 x 128 tiled kernel with the packed bf16 epilogue
+  //   otherwise           : 128 x 128 tiled kernel with the packed bf16 epilogue (pooling dX, K=200: 0.77 vs 1.02 ms)
   static const bool no_wide = getenv("NR_NT_NOWIDE") != nullptr;
   static const bool no_dma = getenv("NR_NT_NODMA") != nullptr;
   const int kr32 = (K + 31) / 32 * 32;
   const bool dense_bf16 = dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0 && ep.rows_out == nullptr;
-  if (dense_bf16 && !no_dma && K >= 512 && ldb >= kr32 && A.ld >= K) {
+  static const int dma_min_k = getenv("NR_DMA_MIN_K") ? atoi(getenv("NR_DMA_MIN_K")) : 256;
+  if (dense_bf16 && !no_dma && K >= dma_min_k && ldb >= kr32 && A.ld >= K) {
     // B must be zero beyond K up to the next multiple of 32 (nr_cast_pad with such an ld guarantees it)
     NrProfScope ps(stream, "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d]", epi, M, N, K);
     const int c13 = ((N + 207) / 208) * 13, c20 = ((N + 319) / 320) * 20;   // fewer padded column tiles wins
