@@ -108,6 +108,8 @@ def pmc_traffic(label):
     want = next((v for k, v in key.items() if label.startswith(k)), None)
     if want is None:
         return None
+    if label.startswith("gemm_nt_dma") and "epi=" in label:      # one instantiation per epilogue: <EPI, NT16, PK>
+        want += "<" + label.split("epi=")[1].split(",")[0] + ","
     for k in json.load(open(files[-1]))["kernels"]:
         if want in k["kernel"]:
             return round((k["fetch_GB_x2_gfx950_16B_correction"] + k["write_GB"]) * 1e9)

@@ -435,13 +435,13 @@ __device__ __forceinline__ bf16x4 trd(const bf16_t* p) { return __builtin_amdgcn
 // A head slice [L, d] travels global -> 4 x 8-byte registers per lane -> swizzled LDS image.  The two halves are
 // separate so the NEXT (sequence, head) slice can be in flight while the current one is being computed.
 struct Slice { bf16x4 v[4]; };
-__device__ __forceinline__ void slice_load(Slice& s, const bf16_t* __restrict__ src, size_t ld, int L, int d, int lane) {
+__device__ __forceinline__ void slice_load(Slice& s, const bf16_t* __restrict__ src, int ld, int L, int d, int lane) {
   const int r = lane & 31, part = lane >> 5;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c = 4 * (2 * q + part);
     s.v[q] = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-    if (r < L && c < d) s.v[q] = *reinterpret_cast<const bf16x4*>(src + (size_t)r * ld + c);
+    if (r < L && c < d) s.v[q] = *reinterpret_cast<const bf16x4*>(src + (uint32_t)(r * ld + c));
   }
 }
 template <bool DROP>
@@ -453,9 +453,9 @@ __device__ __forceinline__ void slice_put(const Slice& s, int L, int d, bf16_t* 
     const int c = 4 * (2 * q + part);
     bf16x4 v = s.v[q];
     if (DROP && drop.thresh && r < L && c < d) {
-      const uint32_t e0 = eidx0 + (uint32_t)r * erow + (uint32_t)c;
+      const uint32_t kb = nr_keep4(drop.key, eidx0 + (uint32_t)r * erow + (uint32_t)c, drop.thresh);   // index is even (d % 4 == 0)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = nr_keep(drop.key, e0 + e, drop.thresh) ? (bf16_t)((float)v[e] * drop.scale) : (bf16_t)0.f;
+      for (int e = 0; e < 4; ++e) v[e] = ((kb >> e) & 1u) ? (bf16_t)((float)v[e] * drop.scale) : (bf16_t)0.f;
     }
     *reinterpret_cast<bf16x4*>(img + ioff(r, c)) = v;
   }
@@ -500,7 +500,7 @@ __device__ __forceinline__ void acc_to_img_t(const f32x16& acc, float mul, bf16_
 
 // transposed image Ot[c][row] -> global rows, 4 columns (8 bytes) per lane and store
 template <bool DROP>
-__device__ __forceinline__ void img_t_to_global(const bf16_t* Ot, bf16_t* __restrict__ dst, size_t ld, int L, int d, int lane,
+__device__ __forceinline__ void img_t_to_global(const bf16_t* Ot, bf16_t* __restrict__ dst, int ld, int L, int d, int lane,
                                                 const DropCfg& drop, uint32_t eidx0, uint32_t erow) {
   const int g16 = lane >> 4, part = g16 >> 1, rb = 16 * (g16 & 1), qq = (lane & 15) >> 2, pp = lane & 3, r = lane & 31;
 #pragma unroll
@@ -509,15 +509,67 @@ __device__ __forceinline__ void img_t_to_global(const bf16_t* Ot, bf16_t* __rest
     bf16x4 v = trd(Ot + ioff(c + qq, rb + 4 * pp));   // executed by every lane (EXEC must be full)
     if (r < L && c < d) {
       if (DROP && drop.thresh) {
-        const uint32_t e0 = eidx0 + (uint32_t)r * erow + (uint32_t)c;
+        const uint32_t kb = nr_keep4(drop.key, eidx0 + (uint32_t)r * erow + (uint32_t)c, drop.thresh);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = nr_keep(drop.key, e0 + e, drop.thresh) ? (bf16_t)((float)v[e] * drop.scale) : (bf16_t)0.f;
+        for (int e = 0; e < 4; ++e) v[e] = ((kb >> e) & 1u) ? (bf16_t)((float)v[e] * drop.scale) : (bf16_t)0.f;
       }
-      *reinterpret_cast<bf16x4*>(dst + (size_t)r * ld + c) = v;
+      *reinterpret_cast<bf16x4*>(dst + (uint32_t)(r * ld + c)) = v;
     }
   }
 }
 
+// acc[col c][row... transposed product: acc[c][i] += sum_j Bm[j][c] X[j][i] -- the operands of mm_xt with their roles swapped, so
+// the lane owns query/token i and its registers hold 4 CONSECUTIVE columns c = 8k + 4h .. +3 per group k: the result
+// goes to global memory as 8-byte pieces straight from the accumulators (no LDS transposition, images stay clean).
+__device__ __forceinline__ void mm_xt_T(f32x16& acc, const f32x16& x, const bf16_t* Bm, int lane) {
+  const int g16 = lane >> 4, h = g16 >> 1, cb = 16 * (g16 & 1), qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = (bf16_t)x[8 * s + e];
+    const bf16x4 lo = trd(Bm + ioff(16 * s + 4 * h + qq, cb + 4 * pp));
+    const bf16x4 hi = trd(Bm + ioff(16 * s + 8 + 4 * h + qq, cb + 4 * pp));
+    const bf16x8 b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc, 0, 0, 0);
+  }
+}
+template <bool DROP>
+__device__ __forceinline__ void acc_t_to_global(const f32x16& acc, bf16_t* __restrict__ dst, int ld, int L, int d, int lane,
+                                                const DropCfg& drop, uint32_t eidx0, uint32_t erow) {
+  const int i = lane & 31, h = lane >> 5;
+  if (i >= L) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 8 * k + 4 * h;
+    if (c < d) {
+      float f[4] = {acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]};
+      if (DROP && drop.thresh) {
+        const uint32_t kb = nr_keep4(drop.key, eidx0 + (uint32_t)i * erow + (uint32_t)c, drop.thresh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = ((kb >> e) & 1u) ? f[e] * drop.scale : 0.f;
+      }
+      const bf16x4 v = {(bf16_t)f[0], (bf16_t)f[1], (bf16_t)f[2], (bf16_t)f[3]};
+      *reinterpret_cast<bf16x4*>(dst + (uint32_t)(i * ld + c)) = v;
+    }
+  }
+}
+
+// Work items of a workgroup: sequences blockIdx.x, +gridDim.x, ... and, inside a sequence, AW heads at a time.
+// Plain int counters (no 64-bit division in the loop).
+struct ItemIter {
+  int sb, hg;
+  __device__ __forceinline__ void next(int hgroups, int stride) {
+    if (++hg == hgroups) { hg = 0; sb += stride; }
+  }
+};
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+// The kernels are VALU-issue bound (4 MFMAs vs ~500 vector instructions per item), so: softmax scale and log2(e) are
+// folded into one fma feeding v_exp_f32, the mask multiply only exists when a mask is given, one dropout hash serves
+// two elements, and all lane offsets are 32-bit.
+template <bool HAS_MASK>
 __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -526,90 +578,74 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   float* sMask = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + (size_t)AW * 3 * IMG) + wid * 32;
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
   bf16_t* y = reinterpret_cast<bf16_t*>(a.y);
-  const int N = a.N, L = a.L, d = a.d;
-  const long total = (long)a.n * a.heads;
+  const int N = a.N, L = a.L, d = a.d, N3 = 3 * a.N;
   const int h2 = lane >> 5;
+  const float c1 = a.scale * LOG2E;   // scale > 0: the row maximum can be taken on the raw scores
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
 
   // One workgroup walks ALL heads of a sequence (AW heads at a time) before moving on; the slices of the NEXT item
-  // are loaded into registers while the current item is computed (the kernel is latency bound otherwise).
-  const int hgroups = (a.heads + AW - 1) / AW;
-  const long nitems = (long)a.n * hgroups;
-  auto item_of = [&](long k, int& seq, int& head, bool& active) {   // k-th item of this workgroup
-    const long sb = blockIdx.x + (k / hgroups) * (long)gridDim.x;
-    const int hraw = (int)(k % hgroups) * AW + wid;
-    active = sb < a.n && hraw < a.heads;
-    seq = sb < a.n ? (int)sb : 0;
-    head = active ? hraw : 0;
-  };
-  const long my_items = ((a.n - blockIdx.x + gridDim.x - 1) / gridDim.x) * hgroups;   // blockIdx.x < n by launch
-  (void)nitems;
+  // are loaded into registers while the current item is computed.
+  const int hgroups = (a.heads + AW - 1) / AW, stride = gridDim.x;
+  ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};   // blockIdx.x < n by launch
   Slice rq, rk, rv;
-  {
-    int seq, head; bool active;
-    item_of(0, seq, head, active);
-    const bf16_t* src = qkv + (size_t)seq * L * 3 * N + head * d;
-    const int Ls = active ? L : 0;
-    slice_load(rq, src, 3 * N, Ls, d, lane);
-    slice_load(rk, src + N, 3 * N, Ls, d, lane);
-    slice_load(rv, src + 2 * N, 3 * N, Ls, d, lane);
-  }
-  for (long k = 0; k < my_items; ++k) {
-    int seq, head; bool active;
-    item_of(k, seq, head, active);
-    const size_t row0 = (size_t)seq * L;
+  auto prefetch = [&](const ItemIter& t) {
+    const int head = t.hg * AW + wid;
+    const bool act = t.sb < a.n && head < a.heads;
+    const bf16_t* src = qkv + (size_t)(act ? t.sb : 0) * L * N3 + (act ? head : 0) * d;
+    const int Ls = act ? L : 0;
+    slice_load(rq, src, N3, Ls, d, lane);
+    slice_load(rk, src + N, N3, Ls, d, lane);
+    slice_load(rv, src + 2 * N, N3, Ls, d, lane);
+  };
+  prefetch(nx);
+  for (; it.sb < a.n; it.next(hgroups, stride)) {
+    const int head = it.hg * AW + wid;
+    const bool active = head < a.heads;
+    const size_t row0 = (size_t)it.sb * L;
     const int Ls = active ? L : 0;                       // inactive waves stage zeros and store nothing
     slice_put<false>(rq, Ls, d, sQ, lane, nodrop, 0, 0);
     slice_put<false>(rk, Ls, d, sK, lane, nodrop, 0, 0);
     slice_put<false>(rv, Ls, d, sV, lane, nodrop, 0, 0);
-    if (lane < 32) sMask[lane] = (lane < Ls) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
+    if (HAS_MASK && lane < 32) sMask[lane] = (lane < Ls) ? a.mask[row0 + lane] : 0.f;
     __syncthreads();
-    if (k + 1 < my_items) {
-      int seq2, head2; bool act2;
-      item_of(k + 1, seq2, head2, act2);
-      const bf16_t* src2 = qkv + (size_t)seq2 * L * 3 * N + head2 * d;
-      const int L2 = act2 ? L : 0;
-      slice_load(rq, src2, 3 * N, L2, d, lane);
-      slice_load(rk, src2 + N, 3 * N, L2, d, lane);
-      slice_load(rv, src2 + 2 * N, 3 * N, L2, d, lane);
-    }
+    nx.next(hgroups, stride);
+    if (nx.sb < a.n) prefetch(nx);
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
-    mm_rr(st, sK, sQ, lane);  // S^T[j][i]
+    mm_rr(st, sK, sQ, lane);  // S^T[j][i] (unscaled)
     float m = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      st[r] *= a.scale;
+    for (int r = 0; r < 16; ++r)
       if (rowof(r, h2) < L) m = fmaxf(m, st[r]);
-    }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float mc = m * c1;
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = rowof(r, h2);
-      const float e = (j < L) ? __expf(st[r] - m) * sMask[j] : 0.f;
+      float e = (j < L) ? __builtin_amdgcn_exp2f(fmaf(st[r], c1, -mc)) : 0.f;
+      if (HAS_MASK) e *= sMask[j];
       st[r] = e;
       sum += e;
     }
     sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / (sum + 1e-8f * __expf(-m));
+    const float inv = 1.f / (sum + 1e-8f * __builtin_amdgcn_exp2f(-mc));
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] *= inv;
     f32x16 ctx;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
-    mm_xt(ctx, st, sV, lane);  // ctx[i][c]
-    __syncthreads();
-    acc_to_img_t(ctx, 1.f, sQ, lane);
-    __syncthreads();
-    img_t_to_global<true>(sQ, y + row0 * N + head * d, N, Ls, d, lane, a.drop, (uint32_t)(row0 * N + head * d), (uint32_t)N);
-    __syncthreads();
+    mm_xt_T(ctx, st, sV, lane);  // ctx^T[c][i]
+    const uint32_t e0 = (uint32_t)(row0 * N) + (uint32_t)((active ? head : 0) * d);
+    acc_t_to_global<true>(ctx, y + row0 * N + (active ? head : 0) * d, N, Ls, d, lane, a.drop, e0, (uint32_t)N);
+    __syncthreads();   // keeps the AW waves (heads of one sequence) in step; the images themselves are per wave
   }
 }
 
-__global__ __launch_bounds__(AW * 64) void bwd_kernel(AttnMArgs a) {
+template <bool HAS_MASK>
+__global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void bwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   bf16_t* base = reinterpret_cast<bf16_t*>(smem) + (size_t)wid * 4 * IMG;
@@ -619,86 +655,74 @@ __global__ __launch_bounds__(AW * 64) void bwd_kernel(AttnMArgs a) {
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
   const bf16_t* dy = reinterpret_cast<const bf16_t*>(a.dy);
   bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.dqkv);
-  const int N = a.N, L = a.L, d = a.d;
-  const long total = (long)a.n * a.heads;
+  const int N = a.N, L = a.L, d = a.d, N3 = 3 * a.N;
   const int h2 = lane >> 5, li = lane & 31;
+  const float c1 = a.scale * LOG2E;
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
 
-  const int hgroups = (a.heads + AW - 1) / AW;
-  auto item_of = [&](long k, int& seq, int& head, bool& active) {
-    const long sb = blockIdx.x + (k / hgroups) * (long)gridDim.x;
-    const int hraw = (int)(k % hgroups) * AW + wid;
-    active = sb < a.n && hraw < a.heads;
-    seq = sb < a.n ? (int)sb : 0;
-    head = active ? hraw : 0;
-  };
-  const long my_items = ((a.n - blockIdx.x + gridDim.x - 1) / gridDim.x) * hgroups;
+  const int hgroups = (a.heads + AW - 1) / AW, stride = gridDim.x;
+  ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};
   Slice rq, rk, rv, rg;
-  {
-    int seq, head; bool active;
-    item_of(0, seq, head, active);
-    const size_t r0 = (size_t)seq * L;
-    const bf16_t* src = qkv + r0 * 3 * N + head * d;
+  auto prefetch = [&](const ItemIter& t) {
+    const int head = t.hg * AW + wid;
+    const bool act = t.sb < a.n && head < a.heads;
+    const size_t r0 = (size_t)(act ? t.sb : 0) * L;
+    const int hd = (act ? head : 0) * d;
+    const bf16_t* src = qkv + r0 * N3 + hd;
+    const int Ls = act ? L : 0;
+    slice_load(rq, src, N3, Ls, d, lane);
+    slice_load(rk, src + N, N3, Ls, d, lane);
+    slice_load(rv, src + 2 * N, N3, Ls, d, lane);
+    slice_load(rg, dy + r0 * N + hd, N, Ls, d, lane);
+  };
+  prefetch(nx);
+  for (; it.sb < a.n; it.next(hgroups, stride)) {
+    const int head = it.hg * AW + wid;
+    const bool active = head < a.heads;
+    const size_t row0 = (size_t)it.sb * L;
     const int Ls = active ? L : 0;
-    slice_load(rq, src, 3 * N, Ls, d, lane);
-    slice_load(rk, src + N, 3 * N, Ls, d, lane);
-    slice_load(rv, src + 2 * N, 3 * N, Ls, d, lane);
-    slice_load(rg, dy + r0 * N + head * d, N, Ls, d, lane);
-  }
-  for (long k = 0; k < my_items; ++k) {
-    int seq, head; bool active;
-    item_of(k, seq, head, active);
-    const size_t row0 = (size_t)seq * L;
-    const int Ls = active ? L : 0;
+    const uint32_t e0 = (uint32_t)(row0 * N) + (uint32_t)((active ? head : 0) * d);
     slice_put<false>(rq, Ls, d, sQ, lane, nodrop, 0, 0);
     slice_put<false>(rk, Ls, d, sK, lane, nodrop, 0, 0);
     slice_put<false>(rv, Ls, d, sV, lane, nodrop, 0, 0);
-    slice_put<true>(rg, Ls, d, sG, lane, a.drop, (uint32_t)(row0 * N + head * d), (uint32_t)N);
-    if (lane < 32) sMask[lane] = (lane < Ls) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
+    slice_put<true>(rg, Ls, d, sG, lane, a.drop, e0, (uint32_t)N);
+    if (HAS_MASK && lane < 32) sMask[lane] = (lane < Ls) ? a.mask[row0 + lane] : 0.f;
     __syncthreads();
-    if (k + 1 < my_items) {
-      int seq2, head2; bool act2;
-      item_of(k + 1, seq2, head2, act2);
-      const size_t r2 = (size_t)seq2 * L;
-      const bf16_t* src2 = qkv + r2 * 3 * N + head2 * d;
-      const int L2 = act2 ? L : 0;
-      slice_load(rq, src2, 3 * N, L2, d, lane);
-      slice_load(rk, src2 + N, 3 * N, L2, d, lane);
-      slice_load(rv, src2 + 2 * N, 3 * N, L2, d, lane);
-      slice_load(rg, dy + r2 * N + head2 * d, N, L2, d, lane);
-    }
-    f32x16 dst;  // dS^T (lane = query i)
+    nx.next(hgroups, stride);
+    if (nx.sb < a.n) prefetch(nx);
+    f32x16 dst;  // dS^T (lane = query i), carries the 1/sqrt(d) factor of dQ and dK
     {
       f32x16 st, dpt;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
-      mm_rr(st, sK, sQ, lane);   // S^T[j][i]
+      mm_rr(st, sK, sQ, lane);   // S^T[j][i] (unscaled)
       mm_rr(dpt, sV, sG, lane);  // dP^T[j][i]
       float m = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        st[r] *= a.scale;
+      for (int r = 0; r < 16; ++r)
         if (rowof(r, h2) < L) m = fmaxf(m, st[r]);
-      }
       m = fmaxf(m, __shfl_xor(m, 32, 64));
+      const float mc = m * c1;
       float sum = 0.f, rdu = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = rowof(r, h2);
-        const float e = (j < L) ? __expf(st[r] - m) * sMask[j] : 0.f;
+        float e = (j < L) ? __builtin_amdgcn_exp2f(fmaf(st[r], c1, -mc)) : 0.f;
+        if (HAS_MASK) e *= sMask[j];
         st[r] = e;
         sum += e;
         rdu = fmaf(e, dpt[r], rdu);
       }
       sum += __shfl_xor(sum, 32, 64);
       rdu += __shfl_xor(rdu, 32, 64);
-      const float inv = 1.f / (sum + 1e-8f * __expf(-m));
+      const float inv = 1.f / (sum + 1e-8f * __builtin_amdgcn_exp2f(-mc));
       const float rd = rdu * inv;
+      const float invs = inv * a.scale;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[r] = st[r] * inv * (dpt[r] - rd);
+      for (int r = 0; r < 16; ++r) dst[r] = st[r] * invs * (dpt[r] - rd);
       if (lane < 32) {
-        sM[lane] = m;
+        sM[lane] = mc;
         sInv[lane] = inv;
         sRd[lane] = rd;
       }
@@ -708,34 +732,30 @@ __global__ __launch_bounds__(AW * 64) void bwd_kernel(AttnMArgs a) {
     {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-      mm_xt(dq, dst, sK, lane);   // dQ[i][c] = sum_j dS[i][j] K[j][c]
+      mm_xt_T(dq, dst, sK, lane); // dQ^T[c][i] = sum_j K[j][c] dS[i][j] / sqrt(d)
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-      mm_rr(s, sQ, sK, lane);     // S[i][j]
+      mm_rr(s, sQ, sK, lane);     // S[i][j] (unscaled)
       mm_rr(dp, sG, sV, lane);    // dP[i][j]
-      const float mj = sMask[li];
+      float mj = (li < L) ? 1.f : 0.f;
+      if (HAS_MASK) mj = sMask[li];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = rowof(r, h2);
-        const float pij = __expf(s[r] * a.scale - sM[i]) * mj * sInv[i];
+        const float pij = __builtin_amdgcn_exp2f(fmaf(s[r], c1, -sM[i])) * (mj * sInv[i]);
         s[r] = pij;
-        dp[r] = pij * (dp[r] - sRd[i]);
+        dp[r] = pij * a.scale * (dp[r] - sRd[i]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
-      mm_xt(dk, dp, sQ, lane);    // dK[j][c] = sum_i dS[i][j] Q[i][c]
-      mm_xt(dv, s, sG, lane);     // dV[j][c] = sum_i P[i][j] G[i][c]
+      mm_xt_T(dk, dp, sQ, lane);  // dK^T[c][j] = sum_i Q[i][c] dS[i][j] / sqrt(d)
+      mm_xt_T(dv, s, sG, lane);   // dV^T[c][j] = sum_i G[i][c] P[i][j]
     }
-    __syncthreads();
-    acc_to_img_t(dq, a.scale, sQ, lane);
-    acc_to_img_t(dk, a.scale, sK, lane);
-    acc_to_img_t(dv, 1.f, sV, lane);
-    __syncthreads();
-    bf16_t* op = dqkv + row0 * 3 * N + head * d;
-    img_t_to_global<false>(sQ, op, 3 * N, Ls, d, lane, nodrop, 0, 0);
-    img_t_to_global<false>(sK, op + N, 3 * N, Ls, d, lane, nodrop, 0, 0);
-    img_t_to_global<false>(sV, op + 2 * N, 3 * N, Ls, d, lane, nodrop, 0, 0);
+    bf16_t* op = dqkv + row0 * N3 + (active ? head : 0) * d;
+    acc_t_to_global<false>(dq, op, N3, Ls, d, lane, nodrop, 0, 0);
+    acc_t_to_global<false>(dk, op + N, N3, Ls, d, lane, nodrop, 0, 0);
+    acc_t_to_global<false>(dv, op + 2 * N, N3, Ls, d, lane, nodrop, 0, 0);
     __syncthreads();
   }
 }
@@ -1150,8 +1170,13 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
     return NR_OK;
   }
   const size_t smem = bwd ? AW * (4 * IMG * sizeof(bf16_t) + 128 * sizeof(float)) : AW * (3 * IMG * sizeof(bf16_t) + 32 * sizeof(float));
-  if (bwd) hipLaunchKernelGGL(bwd_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
-  else hipLaunchKernelGGL(fwd_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
+  if (bwd) {
+    if (a.mask) hipLaunchKernelGGL(bwd_kernel<true>, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
+    else hipLaunchKernelGGL(bwd_kernel<false>, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
+  } else {
+    if (a.mask) hipLaunchKernelGGL(fwd_kernel<true>, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
+    else hipLaunchKernelGGL(fwd_kernel<false>, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
+  }
   NR_CHECK_LAUNCH();
   return NR_OK;
 }

@@ -56,18 +56,28 @@ __host__ __device__ __forceinline__ uint32_t nr_mix32(uint32_t x) {
   return x;
 }
 __host__ __device__ __forceinline__ uint32_t nr_drop_key(uint32_t seed) { return nr_mix32(seed * 0x9e3779b9u + 0x7f4a7c15u); }
+// One 32-bit hash serves TWO consecutive elements (16 bits each): the Bernoulli threshold has 2^-16 resolution
+// (p = 0.2 -> 13107/65536) and the kernels, which handle 4 or 8 consecutive elements per lane, hash half as often.
 __host__ __device__ __forceinline__ uint32_t nr_drop_thresh(float p) {
-  double t = (double)p * 4294967296.0;
-  return t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+  double t = (double)p * 65536.0 + 0.5;
+  return t >= 65535.0 ? 65535u : (uint32_t)t;
 }
+__host__ __device__ __forceinline__ uint32_t nr_pair_hash(uint32_t key, uint32_t idx) { return nr_mix32((idx >> 1) ^ key); }
 // returns 1 if element idx is kept
 __host__ __device__ __forceinline__ bool nr_keep(uint32_t key, uint32_t idx, uint32_t thresh) {
-  return nr_mix32(idx ^ key) >= thresh;
+  const uint32_t h = nr_pair_hash(key, idx);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= thresh;
+}
+// keep bits of the 4 consecutive elements e0 .. e0+3 (bit e set = kept); e0 must be EVEN
+__host__ __device__ __forceinline__ uint32_t nr_keep4(uint32_t key, uint32_t e0, uint32_t thresh) {
+  const uint32_t h0 = nr_mix32((e0 >> 1) ^ key), h1 = nr_mix32(((e0 >> 1) + 1u) ^ key);
+  return ((h0 & 0xffffu) >= thresh ? 1u : 0u) | ((h0 >> 16) >= thresh ? 2u : 0u) | ((h1 & 0xffffu) >= thresh ? 4u : 0u) |
+         ((h1 >> 16) >= thresh ? 8u : 0u);
 }
 
 struct DropCfg {
   uint32_t key;     // nr_drop_key(seed)
-  uint32_t thresh;  // drop if hash < thresh ; 0 = dropout off
+  uint32_t thresh;  // drop if the element's 16 hash bits < thresh ; 0 = dropout off
   float scale;      // 1/(1-p)
 };
 static inline DropCfg nr_make_drop(float p, uint32_t seed) {

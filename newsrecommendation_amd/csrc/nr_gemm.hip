@@ -40,11 +40,25 @@ union Chunk {
 // ---- operand row sources ---------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void drop_chunk(Chunk& c, const DropCfg& dr, uint32_t eidx, int col, int Dtrue);
 template <> __device__ __forceinline__ void drop_chunk<float>(Chunk& c, const DropCfg& dr, uint32_t eidx, int col, int Dtrue) {
+  if ((eidx & 1u) == 0) {   // usual case (even row length): two hashes for the four elements
+    const uint32_t kb = nr_keep4(dr.key, eidx, dr.thresh);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (col + e < Dtrue) c.f[e] = ((kb >> e) & 1u) ? c.f[e] * dr.scale : 0.f;
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e)
     if (col + e < Dtrue) c.f[e] = nr_keep(dr.key, eidx + e, dr.thresh) ? c.f[e] * dr.scale : 0.f;
 }
 template <> __device__ __forceinline__ void drop_chunk<bf16_t>(Chunk& c, const DropCfg& dr, uint32_t eidx, int col, int Dtrue) {
+  if ((eidx & 1u) == 0) {
+    const uint32_t kb = nr_keep4(dr.key, eidx, dr.thresh) | (nr_keep4(dr.key, eidx + 4, dr.thresh) << 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (col + e < Dtrue) c.h[e] = ((kb >> e) & 1u) ? (bf16_t)((float)c.h[e] * dr.scale) : (bf16_t)0.f;
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < 8; ++e)
     if (col + e < Dtrue) c.h[e] = nr_keep(dr.key, eidx + e, dr.thresh) ? (bf16_t)((float)c.h[e] * dr.scale) : (bf16_t)0.f;
@@ -206,11 +220,20 @@ __device__ __forceinline__ void emit4(const EpiArgs& ep, int m, int n, int N, f3
     if (id == 0) return;  // padding_idx row receives no gradient
     float* dst = (float*)ep.C + (size_t)id * ep.ldc + n;
     const uint32_t eidx = (uint32_t)m * (uint32_t)ep.Dtrue + (uint32_t)n;
+    uint32_t kb = 0xfu;
+    if (ep.drop.thresh) {
+      if ((eidx & 1u) == 0) {
+        kb = nr_keep4(ep.drop.key, eidx, ep.drop.thresh);
+      } else {
+        kb = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kb |= nr_keep(ep.drop.key, eidx + e, ep.drop.thresh) ? (1u << e) : 0u;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (n + e >= ep.Dtrue) break;
-      float x = v[e];
-      if (ep.drop.thresh) x = nr_keep(ep.drop.key, eidx + e, ep.drop.thresh) ? x * ep.drop.scale : 0.f;
+      const float x = ((kb >> e) & 1u) ? v[e] * ep.drop.scale : 0.f;
       if (x != 0.f) atomicAdd(dst + e, x);
     }
     return;

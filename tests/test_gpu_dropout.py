@@ -32,7 +32,8 @@ def test_nrms_train_mode_matches_oracle_with_same_masks(tag, dt, tol, gtol):
     loss.backward()
     keep = _nrms_masks(cfg, hist.shape[0], seed_in, seed_out)
     frac = float(keep["hist_word"].mean())
-    assert abs(frac - (1 - cfg.drop_rate)) < 0.02, frac       # Bernoulli(1-p)
+    nel, pk = keep["hist_word"].numel(), 1 - cfg.drop_rate
+    assert abs(frac - pk) < max(0.02, 4 * (pk * (1 - pk) / nel) ** 0.5), frac       # Bernoulli(1-p), 4 sigma on tiny cases
     lo, so, go = oracle_run(tag, z, cfg, sd, keep=keep)
     assert_close(loss, lo, tol, name="loss")
     assert_close(score, so, tol, name="score")
