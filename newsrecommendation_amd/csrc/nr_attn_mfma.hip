@@ -566,47 +566,138 @@ struct ItemIter {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
-// The kernels are VALU-issue bound (4 MFMAs vs ~500 vector instructions per item), so: softmax scale and log2(e) are
-// folded into one fma feeding v_exp_f32, the mask multiply only exists when a mask is given, one dropout hash serves
-// two elements, and all lane offsets are 32-bit.
-template <bool HAS_MASK>
+// Cooperative staging.  The AW heads a workgroup works on are ADJACENT in memory: per token row the AW x d columns
+// of Q (or K, V, dy) are one contiguous AW*2d-byte run.  Instead of every wave fetching its own 2d-byte sliver of
+// 32 rows (32 cache lines touched per load instruction), the workgroup loads the [L, AW*d] panel as consecutive
+// 8-byte pieces -- a wave instruction covers ~3 whole rows -- and scatters the pieces into the per-head LDS images.
+// The piece -> (row, head, column) map is the same for every item, so it is computed once per thread.
+// Pad rows/columns of the images are zeroed once: nothing ever overwrites them (outputs leave from registers).
+// PT = pieces per thread and matrix: needs L * AW * d / 4 <= PT * AW * 64  (PT = 3 up to L * d = 768, else 4)
+template <int PT> struct Pieces {
+  int goff3[PT], goff1[PT], loff[PT], hh[PT];   // offsets in a [*, 3N] / [*, N] row-major tensor, in the image block
+  int poff[PT];                                 // offset in a row-major [L][AW*d + 8] output panel
+};
+template <int PT> __device__ __forceinline__ Pieces<PT> make_pieces(int tid, int L, int d, int N, int nimg) {
+  Pieces<PT> pc;
+  const int pph = d >> 2, ppr = AW * pph;            // pieces per head row / per panel row
+  const uint32_t inv_ppr = (65536 + ppr - 1) / ppr, inv_pph = (65536 + pph - 1) / pph;   // exact for p < 1024, divisors <= 40
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const int p = tid + t * AW * 64;
+    const int row = (int)(((uint32_t)p * inv_ppr) >> 16), q = p - row * ppr;
+    const int h = (int)(((uint32_t)q * inv_pph) >> 16), c = 4 * (q - h * pph);
+    const bool ok = row < L;
+    pc.hh[t] = ok ? h : AW;                           // AW = never active
+    pc.goff3[t] = row * 3 * N + 4 * q;
+    pc.goff1[t] = row * N + 4 * q;
+    pc.loff[t] = h * nimg * IMG + ioff(row & 31, c);
+    pc.poff[t] = (row & 31) * (AW * d + 8) + 4 * q;
+  }
+  return pc;
+}
+template <int PT> struct Panel { bf16x4 v[PT]; };
+template <int PT>
+__device__ __forceinline__ void panel_load(Panel<PT>& r, const bf16_t* __restrict__ src, const int (&goff)[PT], const int (&hh)[PT],
+                                           int hcount) {
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    r.v[t] = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (hh[t] < hcount) r.v[t] = *reinterpret_cast<const bf16x4*>(src + (uint32_t)goff[t]);
+  }
+}
+template <bool DROP, int PT>
+__device__ __forceinline__ void panel_put(const Panel<PT>& r, bf16_t* img0, const Pieces<PT>& pc, const DropCfg& drop, uint32_t eidx0) {
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    if (pc.hh[t] < AW) {
+      bf16x4 v = r.v[t];
+      if (DROP && drop.thresh) {
+        const uint32_t kb = nr_keep4(drop.key, eidx0 + (uint32_t)pc.goff1[t], drop.thresh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ((kb >> e) & 1u) ? (bf16_t)((float)v[e] * drop.scale) : (bf16_t)0.f;
+      }
+      *reinterpret_cast<bf16x4*>(img0 + pc.loff[t]) = v;
+    }
+  }
+}
+__device__ __forceinline__ void zero_images(bf16_t* imgs, int count, int tid) {
+  for (int i = tid; i < count * IMG / 8; i += AW * 64) reinterpret_cast<uint4*>(imgs)[i] = make_uint4(0, 0, 0, 0);
+}
+
+// Outputs leave the same way they came: each wave drops its head's [L, d] result (lane = token, registers = 4-column
+// pieces, see mm_xt_T) into a row-major [L][AW*d (+8 pad)] LDS panel, and after the barrier the workgroup stores the
+// panel as consecutive 8-byte pieces.
+template <bool DROP>
+__device__ __forceinline__ void acc_t_to_panel(const f32x16& acc, bf16_t* panel, int ops, int wid, int L, int d, int lane,
+                                               const DropCfg& drop, uint32_t eidx0, uint32_t erow) {
+  const int i = lane & 31, h = lane >> 5;
+  if (i >= L) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = 8 * k + 4 * h;
+    if (c < d) {
+      float f[4] = {acc[4 * k], acc[4 * k + 1], acc[4 * k + 2], acc[4 * k + 3]};
+      if (DROP && drop.thresh) {
+        const uint32_t kb = nr_keep4(drop.key, eidx0 + (uint32_t)i * erow + (uint32_t)c, drop.thresh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = ((kb >> e) & 1u) ? f[e] * drop.scale : 0.f;
+      }
+      const bf16x4 v = {(bf16_t)f[0], (bf16_t)f[1], (bf16_t)f[2], (bf16_t)f[3]};
+      *reinterpret_cast<bf16x4*>(panel + i * ops + wid * d + c) = v;
+    }
+  }
+}
+template <int PT>
+__device__ __forceinline__ void panel_store(const bf16_t* panel, bf16_t* __restrict__ dst, const int (&goff)[PT],
+                                            const Pieces<PT>& pc, int hcount) {
+#pragma unroll
+  for (int t = 0; t < PT; ++t)
+    if (pc.hh[t] < hcount) *reinterpret_cast<bf16x4*>(dst + (uint32_t)goff[t]) = *reinterpret_cast<const bf16x4*>(panel + pc.poff[t]);
+}
+
+// softmax scale and log2(e) are folded into one fma feeding v_exp_f32; the mask multiply only exists when a mask is
+// given; one dropout hash serves two elements; all lane offsets are 32-bit.
+template <bool HAS_MASK, int PT>
 __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  bf16_t* base = reinterpret_cast<bf16_t*>(smem) + (size_t)wid * 3 * IMG;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  bf16_t* img0 = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* base = img0 + (size_t)wid * 3 * IMG;
   bf16_t *sQ = base, *sK = base + IMG, *sV = base + 2 * IMG;
-  float* sMask = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + (size_t)AW * 3 * IMG) + wid * 32;
+  float* sMask = reinterpret_cast<float*>(img0 + (size_t)AW * 3 * IMG) + wid * 32;
+  bf16_t* sOut = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(img0 + (size_t)AW * 3 * IMG) + AW * 32);   // [32][ops]
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
   bf16_t* y = reinterpret_cast<bf16_t*>(a.y);
-  const int N = a.N, L = a.L, d = a.d, N3 = 3 * a.N;
+  const int N = a.N, L = a.L, d = a.d, N3 = 3 * a.N, ops = AW * a.d + 8;
   const int h2 = lane >> 5;
   const float c1 = a.scale * LOG2E;   // scale > 0: the row maximum can be taken on the raw scores
-  DropCfg nodrop;
-  nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
+  const Pieces<PT> pc = make_pieces<PT>(tid, L, d, N, 3);
+  zero_images(img0, AW * 3, tid);
 
-  // One workgroup walks ALL heads of a sequence (AW heads at a time) before moving on; the slices of the NEXT item
+  // One workgroup walks ALL heads of a sequence (AW heads at a time) before moving on; the panels of the NEXT item
   // are loaded into registers while the current item is computed.
   const int hgroups = (a.heads + AW - 1) / AW, stride = gridDim.x;
   ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};   // blockIdx.x < n by launch
-  Slice rq, rk, rv;
+  Panel<PT> rq, rk, rv;
   auto prefetch = [&](const ItemIter& t) {
-    const int head = t.hg * AW + wid;
-    const bool act = t.sb < a.n && head < a.heads;
-    const bf16_t* src = qkv + (size_t)(act ? t.sb : 0) * L * N3 + (act ? head : 0) * d;
-    const int Ls = act ? L : 0;
-    slice_load(rq, src, N3, Ls, d, lane);
-    slice_load(rk, src + N, N3, Ls, d, lane);
-    slice_load(rv, src + 2 * N, N3, Ls, d, lane);
+    const bf16_t* src = qkv + (size_t)t.sb * L * N3 + t.hg * AW * d;
+    const int hcount = min(AW, a.heads - t.hg * AW);
+    panel_load(rq, src, pc.goff3, pc.hh, hcount);
+    panel_load(rk, src + N, pc.goff3, pc.hh, hcount);
+    panel_load(rv, src + 2 * N, pc.goff3, pc.hh, hcount);
   };
   prefetch(nx);
+  DropCfg nodrop;
+  nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
+  __syncthreads();
   for (; it.sb < a.n; it.next(hgroups, stride)) {
     const int head = it.hg * AW + wid;
     const bool active = head < a.heads;
     const size_t row0 = (size_t)it.sb * L;
-    const int Ls = active ? L : 0;                       // inactive waves stage zeros and store nothing
-    slice_put<false>(rq, Ls, d, sQ, lane, nodrop, 0, 0);
-    slice_put<false>(rk, Ls, d, sK, lane, nodrop, 0, 0);
-    slice_put<false>(rv, Ls, d, sV, lane, nodrop, 0, 0);
+    const int Ls = active ? L : 0;                       // inactive waves store nothing
+    panel_put<false>(rq, img0, pc, nodrop, 0);
+    panel_put<false>(rk, img0 + IMG, pc, nodrop, 0);
+    panel_put<false>(rv, img0 + 2 * IMG, pc, nodrop, 0);
     if (HAS_MASK && lane < 32) sMask[lane] = (lane < Ls) ? a.mask[row0 + lane] : 0.f;
     __syncthreads();
     nx.next(hgroups, stride);
@@ -639,54 +730,56 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
     for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
     mm_xt_T(ctx, st, sV, lane);  // ctx^T[c][i]
     const uint32_t e0 = (uint32_t)(row0 * N) + (uint32_t)((active ? head : 0) * d);
-    acc_t_to_global<true>(ctx, y + row0 * N + (active ? head : 0) * d, N, Ls, d, lane, a.drop, e0, (uint32_t)N);
-    __syncthreads();   // keeps the AW waves (heads of one sequence) in step; the images themselves are per wave
+    acc_t_to_panel<true>(ctx, sOut, ops, wid, Ls, d, lane, a.drop, e0, (uint32_t)N);
+    __syncthreads();   // output panel complete; every wave is done with its images
+    panel_store<PT>(sOut, y + row0 * N + it.hg * AW * d, pc.goff1, pc, min(AW, a.heads - it.hg * AW));
   }
 }
 
-template <bool HAS_MASK>
+template <bool HAS_MASK, int PT>
 __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void bwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  bf16_t* base = reinterpret_cast<bf16_t*>(smem) + (size_t)wid * 4 * IMG;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  bf16_t* img0 = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* base = img0 + (size_t)wid * 4 * IMG;
   bf16_t *sQ = base, *sK = base + IMG, *sV = base + 2 * IMG, *sG = base + 3 * IMG;
-  float* sF = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + (size_t)AW * 4 * IMG) + wid * 128;
+  float* sF = reinterpret_cast<float*>(img0 + (size_t)AW * 4 * IMG) + wid * 128;
   float *sMask = sF, *sM = sF + 32, *sInv = sF + 64, *sRd = sF + 96;
+  const int N = a.N, L = a.L, d = a.d, N3 = 3 * a.N;
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
   const bf16_t* dy = reinterpret_cast<const bf16_t*>(a.dy);
   bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.dqkv);
-  const int N = a.N, L = a.L, d = a.d, N3 = 3 * a.N;
   const int h2 = lane >> 5, li = lane & 31;
   const float c1 = a.scale * LOG2E;
-  DropCfg nodrop;
-  nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
+  const Pieces<PT> pc = make_pieces<PT>(tid, L, d, N, 4);
+  zero_images(img0, AW * 4, tid);
 
   const int hgroups = (a.heads + AW - 1) / AW, stride = gridDim.x;
   ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};
-  Slice rq, rk, rv, rg;
+  Panel<PT> rq, rk, rv, rg;
   auto prefetch = [&](const ItemIter& t) {
-    const int head = t.hg * AW + wid;
-    const bool act = t.sb < a.n && head < a.heads;
-    const size_t r0 = (size_t)(act ? t.sb : 0) * L;
-    const int hd = (act ? head : 0) * d;
+    const size_t r0 = (size_t)t.sb * L;
+    const int hd = t.hg * AW * d;
     const bf16_t* src = qkv + r0 * N3 + hd;
-    const int Ls = act ? L : 0;
-    slice_load(rq, src, N3, Ls, d, lane);
-    slice_load(rk, src + N, N3, Ls, d, lane);
-    slice_load(rv, src + 2 * N, N3, Ls, d, lane);
-    slice_load(rg, dy + r0 * N + hd, N, Ls, d, lane);
+    const int hcount = min(AW, a.heads - t.hg * AW);
+    panel_load(rq, src, pc.goff3, pc.hh, hcount);
+    panel_load(rk, src + N, pc.goff3, pc.hh, hcount);
+    panel_load(rv, src + 2 * N, pc.goff3, pc.hh, hcount);
+    panel_load(rg, dy + r0 * N + hd, pc.goff1, pc.hh, hcount);
   };
   prefetch(nx);
+  DropCfg nodrop;
+  nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
+  __syncthreads();
   for (; it.sb < a.n; it.next(hgroups, stride)) {
     const int head = it.hg * AW + wid;
     const bool active = head < a.heads;
     const size_t row0 = (size_t)it.sb * L;
     const int Ls = active ? L : 0;
-    const uint32_t e0 = (uint32_t)(row0 * N) + (uint32_t)((active ? head : 0) * d);
-    slice_put<false>(rq, Ls, d, sQ, lane, nodrop, 0, 0);
-    slice_put<false>(rk, Ls, d, sK, lane, nodrop, 0, 0);
-    slice_put<false>(rv, Ls, d, sV, lane, nodrop, 0, 0);
-    slice_put<true>(rg, Ls, d, sG, lane, a.drop, e0, (uint32_t)N);
+    panel_put<false>(rq, img0, pc, nodrop, 0);
+    panel_put<false>(rk, img0 + IMG, pc, nodrop, 0);
+    panel_put<false>(rv, img0 + 2 * IMG, pc, nodrop, 0);
+    panel_put<true>(rg, img0 + 3 * IMG, pc, a.drop, (uint32_t)(row0 * N) + (uint32_t)(it.hg * AW * d));
     if (HAS_MASK && lane < 32) sMask[lane] = (lane < Ls) ? a.mask[row0 + lane] : 0.f;
     __syncthreads();
     nx.next(hgroups, stride);
@@ -752,6 +845,8 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       mm_xt_T(dk, dp, sQ, lane);  // dK^T[c][j] = sum_i Q[i][c] dS[i][j] / sqrt(d)
       mm_xt_T(dv, s, sG, lane);   // dV^T[c][j] = sum_i G[i][c] P[i][j]
     }
+    // stored straight from the registers: routing dQ/dK/dV through LDS panels like the forward output measured
+    // slower here (1.38 vs 1.18 ms)
     bf16_t* op = dqkv + row0 * N3 + (active ? head : 0) * d;
     acc_t_to_global<false>(dq, op, N3, Ls, d, lane, nodrop, 0, 0);
     acc_t_to_global<false>(dk, op + N, N3, Ls, d, lane, nodrop, 0, 0);
@@ -1169,13 +1264,17 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
     NR_CHECK_LAUNCH();
     return NR_OK;
   }
-  const size_t smem = bwd ? AW * (4 * IMG * sizeof(bf16_t) + 128 * sizeof(float)) : AW * (3 * IMG * sizeof(bf16_t) + 32 * sizeof(float));
+  const size_t panel = (size_t)32 * (AW * a.d + 8) * sizeof(bf16_t);
+  const size_t smem = bwd ? AW * (4 * IMG * sizeof(bf16_t) + 128 * sizeof(float))
+                          : AW * (3 * IMG * sizeof(bf16_t) + 32 * sizeof(float)) + panel;
+  const bool p3 = a.L * a.d <= 768;
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a); };
   if (bwd) {
-    if (a.mask) hipLaunchKernelGGL(bwd_kernel<true>, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
-    else hipLaunchKernelGGL(bwd_kernel<false>, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
+    if (a.mask) p3 ? go(bwd_kernel<true, 3>) : go(bwd_kernel<true, 4>);
+    else p3 ? go(bwd_kernel<false, 3>) : go(bwd_kernel<false, 4>);
   } else {
-    if (a.mask) hipLaunchKernelGGL(fwd_kernel<true>, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
-    else hipLaunchKernelGGL(fwd_kernel<false>, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a);
+    if (a.mask) p3 ? go(fwd_kernel<true, 3>) : go(fwd_kernel<true, 4>);
+    else p3 ? go(fwd_kernel<false, 3>) : go(fwd_kernel<false, 4>);
   }
   NR_CHECK_LAUNCH();
   return NR_OK;
