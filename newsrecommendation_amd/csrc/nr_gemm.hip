@@ -949,16 +949,21 @@ __device__ __forceinline__ void dma16(const void* gsrc, uint32_t lds_dst) {
 }
 __device__ __forceinline__ int swzP(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }
 
-constexpr int DBM = 256;   // rows per workgroup of the DMA kernel: 8 waves x 32 rows, every wave spans all N columns
+// ring depth of the DMA kernel: 4 stages when they fit (150 KB for the one-per-CU tile, 78 KB when two workgroups share a CU)
+constexpr int dma_ring_stages(int stage_bytes, int wm) { return 4 * stage_bytes <= (wm == 4 ? 150 : 78) * 1024 ? 4 : 3; }
 
-template <int EPI, int NT16, bool PK>
-__global__ __launch_bounds__(WTHR) void gemm_nt_dma_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
+template <int EPI, int NT16, bool PK, int WM>
+__global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                            int ldb, int M, int Ntot, int K, EpiArgs ep, int nchunks) {
+  // WM row groups of 64 rows x 2 column halves = 2*WM waves.  WM = 4: 256-row tile, one workgroup per CU.
+  // WM = 2: 128-row tile whose ring fits twice into the CU's LDS, so one workgroup's pipeline fill and epilogue
+  // overlap the other's MFMA loop.
+  constexpr int DBM = 64 * WM, NW = 2 * WM, WTHR = 128 * WM;
   constexpr int WBN = NT16 * 16;
   constexpr int NP = DBM / 16 + NT16;            // 1-KB DMA pieces per stage (A rows, then B rows)
-  constexpr int PB = NP / 8, PX = NP % 8;        // a wave issues PB (+1 if wid < PX) pieces per stage
+  constexpr int PB = NP / NW, PX = NP % NW;      // a wave issues PB (+1 if wid < PX) pieces per stage
   constexpr int STAGE = NP * 1024;               // bytes per ring stage
-  constexpr int NS = (4 * STAGE <= 150 * 1024) ? 4 : 3;
+  constexpr int NS = dma_ring_stages(STAGE, WM);
   constexpr int SCW = WBN + 4;
   constexpr int AB = DBM * 64;                   // byte offset of the B tile inside a stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1060,7 +1065,7 @@ __global__ __launch_bounds__(WTHR) void gemm_nt_dma_kernel(const bf16_t* __restr
     bf16_t* sCb = reinterpret_cast<bf16_t*>(smem);
     constexpr int SCB = WBN + 8;
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < WM / 2; ++pass) {
       if (pass) __syncthreads();
       if ((wm >> 1) == pass) {
 #pragma unroll
@@ -1113,7 +1118,7 @@ __global__ __launch_bounds__(WTHR) void gemm_nt_dma_kernel(const bf16_t* __restr
   }
   // epilogue: 32 rows at a time through the fp32 LDS tile (pass p = rows 32p..32p+31 = wave row wm = p>>1, tiles 2(p&1), +1)
 #pragma unroll 1
-  for (int pass = 0; pass < 8; ++pass) {
+  for (int pass = 0; pass < 2 * WM; ++pass) {
     if (pass) __syncthreads();
     if (wm == (pass >> 1)) {
 #pragma unroll
@@ -1144,20 +1149,30 @@ __global__ __launch_bounds__(WTHR) void gemm_nt_dma_kernel(const bf16_t* __restr
   }
 }
 
-template <int EPI, int NT16, bool PK>
-int launch_nt_dma_p(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
-  constexpr int NP = DBM / 16 + NT16, STAGE = NP * 1024, NS = (4 * STAGE <= 150 * 1024) ? 4 : 3;
+template <int EPI, int NT16, bool PK, int WM>
+int launch_nt_dma_w(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
+  constexpr int DBM = 64 * WM, NP = DBM / 16 + NT16, STAGE = NP * 1024, NS = dma_ring_stages(STAGE, WM);
   constexpr size_t ring = (size_t)NS * STAGE, epi = (size_t)32 * (NT16 * 16 + 4) * sizeof(float);
-  constexpr size_t epk = (size_t)128 * (NT16 * 16 + 8) * sizeof(bf16_t);
+  constexpr size_t epk = PK ? (size_t)128 * (NT16 * 16 + 8) * sizeof(bf16_t) : 0;
   constexpr size_t smem0 = ring > epi ? ring : epi, smem = smem0 > epk ? smem0 : epk;
-  auto kern = gemm_nt_dma_kernel<EPI, NT16, PK>;
+  auto kern = gemm_nt_dma_kernel<EPI, NT16, PK, WM>;
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   const int tilesM = (M + DBM - 1) / DBM, nchunks = (N + NT16 * 16 - 1) / (NT16 * 16);
   const int grid = ((tilesM + 7) / 8) * 8 * nchunks;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(WTHR), smem, stream, (const bf16_t*)A.base, A.ld, (const bf16_t*)B, ldb, M, N, K, ep,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), smem, stream, (const bf16_t*)A.base, A.ld, (const bf16_t*)B, ldb, M, N, K, ep,
                      nchunks);
   NR_CHECK_LAUNCH();
   return NR_OK;
+}
+
+template <int EPI, int NT16, bool PK>
+int launch_nt_dma_p(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
+  // two 128-row workgroups per CU when three ring stages of the small tile fit twice into LDS and the whole N is one
+  // column chunk (att_fc1: 0.47 -> 0.41 ms); with several chunks the smaller tile re-reads A more often and loses
+  // (QKV projection: 1.45 -> 1.57 ms)
+  constexpr bool fits2 = 3 * (8 + NT16) * 1024 <= 78 * 1024;
+  if (fits2 && N <= NT16 * 16) return launch_nt_dma_w<EPI, NT16, PK, 2>(A, B, ldb, M, N, K, ep, stream);
+  return launch_nt_dma_w<EPI, NT16, PK, 4>(A, B, ldb, M, N, K, ep, stream);
 }
 
 template <int EPI, int NT16>
