@@ -1028,17 +1028,66 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
     if (s < nk) issue(s, s * BK);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int rem = min(NS - 2, nk - 1 - kt);    // stages issued after stage kt that may stay in flight
+  // wait until at most `stages` of this wave's most recent stage issues are still in flight
+  auto wait_stages = [&](int stages) {
     if (extra) {
-      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PB + 1)) : "memory");
-      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB + 1) : "memory");
+      if (stages >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PB + 1)) : "memory");
+      else if (stages == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB + 1) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PB) : "memory");
-      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB) : "memory");
+      if (stages >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PB) : "memory");
+      else if (stages == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+  };
+  constexpr bool PF = (NS == 4) && (HN <= 7);    // fragment double buffering fits the register file
+  if constexpr (PF) {
+    // The fragments of k-step kt+1 are read from LDS while the MFMAs of k-step kt run, so the LDS latency and the
+    // burst of 8 waves reading at once no longer sit between the barrier and the first MFMA.  Costs one stage of
+    // DMA lead (stage kt+1 must have landed at step kt).
+    bf16x8 fa[2][4], fb[2][HN];
+    auto load_frags = [&](int buf, int stage) {
+      const char* st = smem + stage * STAGE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[buf][i] = *reinterpret_cast<const bf16x8*>(st + offA[i]);
+#pragma unroll
+      for (int j = 0; j < HN; ++j)
+        if (wn * HN + j < NT16) fb[buf][j] = *reinterpret_cast<const bf16x8*>(st + offB + j * 1024);
+    };
+    auto mfmas = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < HN; ++j) {
+        if (wn * HN + j < NT16) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (PK) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    };
+    auto step = [&](int kt, int cur) {
+      if (kt + 1 < nk) {
+        wait_stages(min(NS - 3, nk - 2 - kt));   // stage kt+1 landed (stages kt+2.. may be in flight)
+        __builtin_amdgcn_s_barrier();
+        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
+        load_frags(cur ^ 1, (kt + 1) % NS);
+      }
+      mfmas(cur);
+    };
+    wait_stages(min(NS - 2, nk - 1));
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, 0);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      step(kt, 0);
+      step(kt + 1, 1);
+    }
+    if (kt < nk) step(kt, 0);
+  } else {
+  for (int kt = 0; kt < nk; ++kt) {
+    const int rem = min(NS - 2, nk - 1 - kt);    // stages issued after stage kt that may stay in flight
+    wait_stages(rem);
     __builtin_amdgcn_s_barrier();
     if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
     const char* st = smem + (kt % NS) * STAGE;
@@ -1057,6 +1106,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
         }
       }
     }
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
