@@ -90,7 +90,7 @@ def attn_bytes(label, esz):
     m = re.search(r"n=(\d+),L=(\d+),h=(\d+),d=(\d+)", label)
     n, L, h, d = (int(x) for x in m.groups())
     rows, N = n * L, h * d
-    if label.startswith("attn_fwd"):
+    if "_fwd" in label.split("[")[0]:
         return rows * (3 * N + N) * esz            # read Q|K|V, write y
     return rows * (3 * N + N + 3 * N) * esz        # read Q|K|V + dy, write dQ|dK|dV
 
@@ -103,7 +103,7 @@ def pmc_traffic(label):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")))
     if not files:
         return None
-    key = {"gemm_nt[": "gemm_nt_kernelIDF16bLi0ELi0", "gemm_nt_dma": "gemm_nt_dma_kernel", "gemm_tn2": "tn2::gemm_tn2_kernel",
+    key = {"gemm_nt[": "gemm_nt_kernelIDF16bLi0ELi0", "gemm_nt_dma": "gemm_nt_dma_kernel", "gemm_tn2": "tn2::gemm_tn2_kernel", "gemm_tn3": "tn3::gemm_tn3_kernel",
            "attn_mfma_bwd": "b16::bwd_kernel", "attn_mfma_fwd": "b16::fwd_kernel", "gemm_nt_wide": "gemm_nt_wide_kernel"}
     want = next((v for k, v in key.items() if label.startswith(k)), None)
     if want is None:

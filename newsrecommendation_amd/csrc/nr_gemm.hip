@@ -1243,6 +1243,219 @@ int launch_nt_dma_e(const RowSrc& A, const void* B, int ldb, int M, int N, int K
   return NR_ERR_ARG;
 }
 
+// =========================================================================================
+// TN on the LDS-DMA ring (bf16, dense operands, rows a multiple of 32): dW[n][k] += sum_m dC[m][n] X[m][k].
+// Same math and LDS images as tn2 (operands stay row-major as they lie in memory, fragments come out of
+// ds_read_b64_tr_b16, swizzles on the 16-byte chunk index), but the tiles travel global -> LDS with
+// global_load_lds_dwordx4 into a 4-stage ring of 32-row slabs, 3 stages in flight, no staging registers: the
+// contraction over M = 844 800 rows is all main loop, and the register-staged version kept one slab in flight.
+// Block tile 128 (n) x 80*WK (k): WK = 4 covers K <= 320 in one tile (dC, the 2 GB operand of the QKV weight
+// gradient, is read once), 8 waves, one workgroup per CU; WK = 2: 4 waves, two workgroups per CU.
+// Column tails are clamped to valid chunks (they only feed outputs that are never stored).
+// db: two waves (on different SIMDs) run one extra MFMA per A fragment against a vector of ones.
+// =========================================================================================
+namespace tn3 {
+using tn2::swz_a;
+using tn2::tr_frag;
+constexpr int TBN = 128, TBM = 32, NS = 4;
+template <int WK> struct Geo {
+  static constexpr int TBK = 80 * WK, NT = 128 * WK, NW = 2 * WK, CH = TBK / 8, SCW = TBK + 4;
+  static constexpr int PA = TBM * 16 / 64, PBP = TBM * CH / 64, NP = PA + PBP, STAGE = NP * 1024;
+  static constexpr size_t RING = (size_t)NS * STAGE, EPI = (size_t)64 * SCW * sizeof(float);
+  static constexpr size_t SMEM = RING > EPI ? RING : EPI;
+};
+// X tile rows are 320 B (WK=2) or 640 B (WK=4) apart: the 4 rows of a 16-lane group and the odd/even 8-row groups
+// must land on different 32-byte segments of a 256-byte bank window
+template <int WK> __device__ __forceinline__ int swz_b(int row, int chunk) {
+  return WK == 2 ? chunk ^ (2 * ((row >> 3) & 1)) : chunk ^ (4 * ((row >> 1) & 1) + 2 * ((row >> 3) & 1));
+}
+
+template <int WK>
+__global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __restrict__ dC, int ldc, const bf16_t* __restrict__ X,
+                                                            int ldx, float* __restrict__ dW, int ldw, float* __restrict__ db,
+                                                            int M, int N, int K, int Nstore, int Kstore, int tilesK, int ntile,
+                                                            int nsplit, int rps) {
+  using G = Geo<WK>;
+  constexpr int TBK = G::TBK, NT = G::NT, NW = G::NW, CH = G::CH, SCW = G::SCW, PA = G::PA, NP = G::NP, STAGE = G::STAGE;
+  constexpr int PB = NP / NW, PX = NP % NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sC = reinterpret_cast<float*>(smem);
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+  // XCD-aware: the ntile workgroups of one split (same rows of dC / X) sit on one XCD back to back
+  const int b = blockIdx.x, xcd = b & 7, local = b >> 3;
+  const int split = (local / ntile) * 8 + xcd, tile = local % ntile;
+  if (split >= nsplit) return;
+  const int tn = tile / tilesK, tk = tile % tilesK;
+  const int n0 = tn * TBN, k0 = tk * TBK;
+  const int mbeg = split * rps, mend = min(M, mbeg + rps);
+  if (mbeg >= mend) return;
+  const int nk = (mend - mbeg) / TBM;             // exact: M and rps are multiples of TBM (launcher)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid / WK, wn = wid % WK;
+  const bool extra = wid < PX;
+  const int pfirst = wid * PB + min(wid, PX);
+  const bool db_wave = (db != nullptr) && (tk == 0) && (wn == wm);
+
+  const bf16_t* src[PB + 1];
+  size_t adv[PB + 1];
+#pragma unroll
+  for (int t = 0; t < PB + 1; ++t) {
+    const int p = pfirst + t;
+    if (p < PA) {
+      const int P = 64 * p + lane, row = P >> 4, cpos = P & 15;
+      const int col = min(n0 + swz_a(row, cpos) * 8, N - 8);
+      src[t] = dC + (size_t)(mbeg + row) * ldc + col;
+      adv[t] = (size_t)TBM * ldc;
+    } else {
+      const int P = 64 * (p - PA) + lane, row = P / CH, cpos = P - row * CH;
+      const int col = min(k0 + swz_b<WK>(row, cpos) * 8, K - 8);
+      src[t] = X + (size_t)(mbeg + min(row, TBM - 1)) * ldx + col;
+      adv[t] = (size_t)TBM * ldx;
+    }
+  }
+  auto issue = [&](int stage, int kt) {
+#pragma unroll
+    for (int t = 0; t < PB + 1; ++t)
+      if (t < PB || extra) dma16(src[t] + kt * adv[t], lds0 + stage * STAGE + (pfirst + t) * 1024);
+  };
+  auto wait_stages = [&](int stages) {
+    if (extra) {
+      if (stages >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PB + 1)) : "memory");
+      else if (stages == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (stages >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PB) : "memory");
+      else if (stages == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+
+  f32x4 acc[4][5], accdb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accdb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
+
+  // transposed-read lane geometry (see tn2): 16-lane group g holds m rows 8g..8g+7
+  const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int r0 = 8 * g + q, r1 = r0 + 4, off = 4 * (pp & 1);
+  int oa0[4], oa1[4], ob0[5], ob1[5];               // element offsets inside a stage (loop invariant)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int chunk = (wm * 64 + i * 16) / 8 + (pp >> 1);
+    oa0[i] = r0 * TBN + swz_a(r0, chunk) * 8 + off;
+    oa1[i] = r1 * TBN + swz_a(r1, chunk) * 8 + off;
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int chunk = (wn * 80 + j * 16) / 8 + (pp >> 1);
+    ob0[j] = TBM * TBN + r0 * TBK + swz_b<WK>(r0, chunk) * 8 + off;
+    ob1[j] = TBM * TBN + r1 * TBK + swz_b<WK>(r1, chunk) * 8 + off;
+  }
+
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) issue(s, s);
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_stages(min(NS - 2, nk - 1 - kt));
+    __builtin_amdgcn_s_barrier();
+    if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, kt + NS - 1);
+    const bf16_t* st = reinterpret_cast<const bf16_t*>(smem + (kt % NS) * STAGE);
+    bf16x8 af[4], bf[5];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = tr_frag(st + oa0[i], st + oa1[i]);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) bf[j] = tr_frag(st + ob0[j], st + ob1[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    if (db_wave) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accdb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accdb[i], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  if (db_wave && (lane & 15) == 0) {                // every column of accdb holds the row sums
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (n < Nstore) atomicAdd(db + n, accdb[i][r]);
+      }
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
+    if (wm == half) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int col = wn * 80 + j * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sC[(i * 16 + (lane >> 4) * 4 + r) * SCW + col] = acc[i][j][r];
+      }
+    }
+    __syncthreads();
+    for (int u = tid; u < 64 * (TBK / 4); u += NT) {
+      const int row = u / (TBK / 4), c0 = (u % (TBK / 4)) * 4;
+      const int n = n0 + half * 64 + row, k = k0 + c0;
+      if (n < Nstore && k < Kstore) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * SCW + c0);
+        float* dst = dW + (size_t)n * ldw + k;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k + e < Kstore) atomicAdd(dst + e, v[e]);
+      }
+    }
+  }
+}
+
+template <int WK>
+int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
+             int Kstore, hipStream_t stream) {
+  using G = Geo<WK>;
+  const int tilesN = (N + TBN - 1) / TBN, tilesK = (K + G::TBK - 1) / G::TBK, ntile = tilesN * tilesK;
+  // whole rounds of resident workgroups (256 CUs x 1 or 2), splits a multiple of the 8 XCDs, >= 16 slabs per split
+  const int resident = 256 * (WK == 4 ? 1 : 2), rounds = WK == 4 ? 5 : 3;
+  int nsplit = ((resident * rounds / ntile + 4) / 8) * 8;
+  if (nsplit < 8) nsplit = 8;
+  int rps = (M + nsplit - 1) / nsplit;
+  rps = ((rps + TBM - 1) / TBM) * TBM;
+  if (rps < 16 * TBM) rps = 16 * TBM;
+  nsplit = (M + rps - 1) / rps;
+  const int grid = ((nsplit + 7) / 8) * 8 * ntile;
+  auto kern = gemm_tn3_kernel<WK>;
+  NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::SMEM, stream, (const bf16_t*)dC, ldc, (const bf16_t*)X, ldx, dW, ldw, db, M, N,
+                     K, Nstore, Kstore, tilesK, ntile, nsplit, rps);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+// rows a multiple of the 32-row slab, at least 8 columns on both sides (tail clamping), 16-byte aligned rows
+bool eligible(int ldc, int ldx, int M, int N, int K) {
+  static const bool off = getenv("NR_NO_TN3") != nullptr;
+  // long contractions only: at the user level (M = 25 600) the ring fill per split costs more than it hides (0.31 vs 0.18 ms)
+  return !off && M % TBM == 0 && M >= 200000 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0 && ldc % 8 == 0 && ldx % 8 == 0;
+}
+int launch(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
+           int Kstore, hipStream_t stream) {
+  static const int force = [] { const char* e = getenv("NR_TN3_WK"); return e ? atoi(e) : 0; }();
+  const bool wide = force ? force == 4 : (K > 160 && ((K + 319) / 320) * 320 * 100 <= K * 115);
+  if (wide) return launch_t<4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+  return launch_t<2>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+}
+}  // namespace tn3
+
 template <typename T, int KIND, int EPI>
 int launch_nt_t(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
   const int tilesM = (M + BM - 1) / BM, tilesN = (N + BN - 1) / BN;
@@ -1374,6 +1587,10 @@ int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float
   NR_CHECK_ARG(((uintptr_t)A.base & 15) == 0 && ((uintptr_t)dC & 15) == 0, "gemm_tn: operands must be 16-byte aligned");
   static const bool tn_v1 = getenv("NR_TN_V1") != nullptr;
   if (!tn_v1 && dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0) {
+    if (tn3::eligible(ldc, A.ld, M, N, K)) {
+      NrProfScope ps(stream, "gemm_tn3[bf16,M=%d,N=%d,K=%d]", M, N, K);
+      return tn3::launch(dC, ldc, A.base, A.ld, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+    }
     NrProfScope ps(stream, "gemm_tn2[bf16,M=%d,N=%d,K=%d]", M, N, K);
     return tn2::launch(dC, ldc, A.base, A.ld, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
   }
