@@ -74,6 +74,42 @@ void nr_set_error(const char* fmt, ...) {
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- side stream: two independent GEMMs of one backward composite run concurrently -----------------------------
+// The weight-gradient GEMM (LDS/MFMA bound) and the input-gradient GEMM (bound by L2 atomics or output stores)
+// consume the same upstream gradient and do not depend on each other.  fork: the side stream waits for everything
+// enqueued so far on the caller's stream; join: the caller's stream waits for the side stream.  Both are event
+// waits on the device -- nothing blocks on the host, and memory the caller frees after the call is only reused
+// by work ordered behind the join.
+namespace {
+struct SideStream { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; int dev = -1; };
+thread_local SideStream g_side;
+// Opt-in (NR_SIDE_STREAM=1): measured 9.66 -> 9.43 ms/step at the bench shape; off by default because overlapped
+// launches no longer have a per-kernel duration of their own, which the roofline accounting of bench.py relies on.
+bool side_enabled() {
+  static const bool on = [] { const char* e = getenv("NR_SIDE_STREAM"); return e != nullptr && e[0] == '1'; }();
+  return on;
+}
+int side_fork(hipStream_t main, hipStream_t* out) {
+  int dev = 0;
+  NR_CHECK_HIP(hipGetDevice(&dev));
+  if (g_side.s == nullptr || g_side.dev != dev) {
+    NR_CHECK_HIP(hipStreamCreateWithFlags(&g_side.s, hipStreamNonBlocking));
+    NR_CHECK_HIP(hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming));
+    NR_CHECK_HIP(hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming));
+    g_side.dev = dev;
+  }
+  NR_CHECK_HIP(hipEventRecord(g_side.fork, main));
+  NR_CHECK_HIP(hipStreamWaitEvent(g_side.s, g_side.fork, 0));
+  *out = g_side.s;
+  return NR_OK;
+}
+int side_join(hipStream_t main) {
+  NR_CHECK_HIP(hipEventRecord(g_side.join, g_side.s));
+  NR_CHECK_HIP(hipStreamWaitEvent(main, g_side.join, 0));
+  return NR_OK;
+}
+}  // namespace
 static inline bool dtype_ok(int dt) { return dt == NR_F32 || dt == NR_BF16; }
 
 static RowSrc dense_rows(const void* base, int ld, int cols) {
@@ -243,8 +279,13 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
     NR_CHECK_ARG(d->ld_rows >= Kp, "mhsa_bwd: ld_rows=%d must cover %d", d->ld_rows, Kp);
     Xs = dense_rows(d->x_rows, d->ld_rows, d->d_model);
   }
+  const bool want_dx = dx != nullptr || dtable != nullptr;
+  const bool fork = want_dx && side_enabled() && M >= 65536;
+  hipStream_t s2 = s;
+  if (fork && (rc = side_fork(s, &s2))) return rc;
   if ((rc = nr_launch_gemm_tn(d->dtype, dqkv, 3 * N, Xs, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model, s))) return rc;
-  if (dx != nullptr || dtable != nullptr) {
+  if (want_dx) {
+    hipStream_t s = s2;   // the input-gradient GEMM goes to the side stream
     NR_CHECK_ARG(w_qkv_t != nullptr && ldwt >= 3 * N, "mhsa_bwd: w_qkv_t [d_model, >=3N] needed for dx / dtable");
     RowSrc G = dense_rows(dqkv, 3 * N, 3 * N);
     if (d->src_kind == NR_SRC_GATHER) {
@@ -260,6 +301,10 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
       EpiArgs ep = store_epi(dx, d->ldx, d->dtype, nullptr, 0);
       rc = nr_launch_gemm_nt(d->dtype, G, w_qkv_t, ldwt, M, d->d_model, 3 * N, EPI_STORE, ep, s);
     }
+  }
+  if (fork) {
+    const int rj = side_join(s);
+    if (rc == NR_OK) rc = rj;
   }
   return rc;
 }
@@ -339,13 +384,20 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
   if ((rc = nr_launch_pool_core_bwd(d->dtype, d->x, e, d->w2, alpha, g, ld_g, dpre, partial, dw2, db2, d->n, d->L, d->N, d->q, s)))
     return rc;
   RowSrc X = dense_rows(d->x, d->N, d->N);
+  const bool fork = dx != nullptr && side_enabled() && M >= 65536;
+  hipStream_t s2 = s;
+  if (fork && (rc = side_fork(s, &s2))) return rc;
   if ((rc = nr_launch_gemm_tn(d->dtype, dpre, d->q, X, dw1, d->N, db1, M, d->q, d->N, d->q, d->N, s))) return rc;
   if (dx != nullptr) {
     NR_CHECK_ARG(w1_t != nullptr && ldw1t >= d->q, "additive_pool_bwd: w1_t [N, >=q] needed for dx");
     RowSrc P = dense_rows(dpre, d->q, d->q);
     EpiArgs ep = store_epi(dx, d->N, d->dtype, nullptr, 0);
     ep.rowscale = alpha; ep.G = g; ep.ldg = ld_g; ep.L = d->L;
-    rc = nr_launch_gemm_nt(d->dtype, P, w1_t, ldw1t, M, d->N, d->q, EPI_POOLBWD, ep, s);
+    rc = nr_launch_gemm_nt(d->dtype, P, w1_t, ldw1t, M, d->N, d->q, EPI_POOLBWD, ep, s2);
+  }
+  if (fork) {
+    const int rj = side_join(s);
+    if (rc == NR_OK) rc = rj;
   }
   return rc;
 }
