@@ -130,6 +130,10 @@ typedef struct {
   uint32_t seed_in;
   const void* w_pack; /* [N, 3*Dp] dtype (nr_pack_conv_w) */
   const float* bias;  /* [N] */
+  void* x_rows;       /* optional scratch [n*T, ld_rows] dtype: the forward stores the im2col rows (gather + dropout, three
+                         taps side by side) here once and runs a dense GEMM on them; a backward given the same buffer
+                         reuses them.  NULL: the operand is gathered on the fly inside the GEMMs.               */
+  int ld_rows;        /* >= 3*Dp */
 } nr_conv_desc;
 int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream);
 /* dw_pack [N, 3*Dp] fp32 accumulated (nr_unpack_conv_dw -> [N, D, 3]); db [N] accumulated.

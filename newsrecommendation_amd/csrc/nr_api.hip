@@ -334,7 +334,15 @@ int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream) {
   if (d->n == 0) return NR_OK;
   NR_CHECK_ARG(y != nullptr, "conv1d_fwd: null output");
   EpiArgs ep = store_epi(y, d->N, d->dtype, d->bias, 0);
-  return nr_launch_gemm_nt(d->dtype, A, d->w_pack, 3 * d->Dp, d->n * d->T, d->N, 3 * d->Dp, EPI_STORE, ep, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  const int M = d->n * d->T, K = 3 * d->Dp;
+  if (d->x_rows != nullptr) {
+    // im2col rows (gather + dropout hashed once) -> dense operand for the LDS-DMA GEMM
+    NR_CHECK_ARG(d->ld_rows >= K && d->ld_rows % nr_chunk(d->dtype) == 0, "conv1d_fwd: ld_rows=%d must cover %d", d->ld_rows, K);
+    if ((rc = nr_launch_rows_materialize(d->dtype, A, d->x_rows, d->ld_rows, M, K, s))) return rc;
+    A = dense_rows(d->x_rows, d->ld_rows, K);
+  }
+  return nr_launch_gemm_nt(d->dtype, A, d->w_pack, K, M, d->N, K, EPI_STORE, ep, s);
 }
 
 int nr_conv1d_k3_bwd(const nr_conv_desc* d, const void* dy, float* dw_pack, float* db, nr_stream_t stream) {
@@ -343,6 +351,10 @@ int nr_conv1d_k3_bwd(const nr_conv_desc* d, const void* dy, float* dw_pack, floa
   if (rc) return rc;
   if (d->n == 0) return NR_OK;
   NR_CHECK_ARG(dy && dw_pack && db, "conv1d_bwd: null operand");
+  if (d->x_rows != nullptr) {   // the rows the forward stored
+    NR_CHECK_ARG(d->ld_rows >= 3 * d->Dp, "conv1d_bwd: ld_rows=%d must cover %d", d->ld_rows, 3 * d->Dp);
+    A = dense_rows(d->x_rows, d->ld_rows, 3 * d->Dp);
+  }
   return nr_launch_gemm_tn(d->dtype, dy, d->N, A, dw_pack, 3 * d->Dp, db, d->n * d->T, d->N, 3 * d->Dp, d->N, 3 * d->Dp,
                            (hipStream_t)stream);
 }

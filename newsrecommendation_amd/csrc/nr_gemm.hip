@@ -1531,12 +1531,17 @@ int launch_tn_d(const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, fl
 
 int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, int M, int K, hipStream_t stream) {
   const int ch = nr_chunk(dtype);
-  NR_CHECK_ARG(A.kind == ROWS_GATHER && K % ch == 0 && ldo % ch == 0 && ldo >= K, "rows_materialize: bad arguments");
+  NR_CHECK_ARG((A.kind == ROWS_GATHER || A.kind == ROWS_IM2COL3) && K % ch == 0 && ldo % ch == 0 && ldo >= K, "rows_materialize: bad arguments");
   NrProfScope ps(stream, "rows_materialize[%s,M=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", M, K);
   const size_t total = (size_t)M * (K / ch);
   size_t grid = (total + 255) / 256;
   if (grid > 256 * 32) grid = 256 * 32;
-  if (dtype == NR_BF16)
+  if (A.kind == ROWS_IM2COL3) {
+    if (dtype == NR_BF16)
+      hipLaunchKernelGGL((rows_materialize_kernel<bf16_t, ROWS_IM2COL3>), dim3((unsigned)grid), dim3(256), 0, stream, A, (bf16_t*)out, ldo, M, K);
+    else
+      hipLaunchKernelGGL((rows_materialize_kernel<float, ROWS_IM2COL3>), dim3((unsigned)grid), dim3(256), 0, stream, A, (float*)out, ldo, M, K);
+  } else if (dtype == NR_BF16)
     hipLaunchKernelGGL((rows_materialize_kernel<bf16_t, ROWS_GATHER>), dim3((unsigned)grid), dim3(256), 0, stream, A, (bf16_t*)out, ldo, M, K);
   else
     hipLaunchKernelGGL((rows_materialize_kernel<float, ROWS_GATHER>), dim3((unsigned)grid), dim3(256), 0, stream, A, (float*)out, ldo, M, K);

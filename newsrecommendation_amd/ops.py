@@ -332,11 +332,15 @@ class ConvFunction(Function):
         check(_lib.lib().nr_pack_conv_w(ptr(wc), N, D, ptr(w_p), Dp, code, _stream()), "nr_pack_conv_w")
         b_c = b.detach().float().contiguous()
         y = torch.empty(n, T, N, dtype=torch_dtype(code), device=dev)
+        # bf16: the im2col rows (gather + dropout, 3 taps) are stored once and feed the dense LDS-DMA GEMMs of both passes
+        x_rows = torch.empty(n * T, 3 * Dp, dtype=torch.bfloat16, device=dev) if code == _lib.NR_BF16 and n > 0 else None
         d = _lib.ConvDesc(n=n, T=T, D=D, Dp=Dp, N=N, dtype=code, table=ptr(table_p), ids=ids.data_ptr(), ids_stride=stride,
-                          p_in=cfg["p_in"], seed_in=cfg["seed_in"], w_pack=ptr(w_p), bias=ptr(b_c))
+                          p_in=cfg["p_in"], seed_in=cfg["seed_in"], w_pack=ptr(w_p), bias=ptr(b_c), x_rows=ptr(x_rows),
+                          ld_rows=3 * Dp)
         check(_lib.lib().nr_conv1d_k3_fwd(C.byref(d), ptr(y), _stream()), "nr_conv1d_k3_fwd")
         ctx.cfg, ctx.dims = cfg, (n, T, D, Dp, N, stride)
         ctx.ids = ids                                   # keeps the (possibly strided) id view alive
+        ctx.x_rows = x_rows if any(ctx.needs_input_grad[:2]) else None
         ctx.save_for_backward(table_p, w_p, b_c)
         return y
 
@@ -351,7 +355,8 @@ class ConvFunction(Function):
         dwp = torch.zeros(N, 3 * Dp, dtype=torch.float32, device=dev)
         db = torch.zeros(N, dtype=torch.float32, device=dev)
         d = _lib.ConvDesc(n=n, T=T, D=D, Dp=Dp, N=N, dtype=code, table=ptr(table_p), ids=ctx.ids.data_ptr(), ids_stride=stride,
-                          p_in=cfg["p_in"], seed_in=cfg["seed_in"], w_pack=ptr(w_p), bias=ptr(b_c))
+                          p_in=cfg["p_in"], seed_in=cfg["seed_in"], w_pack=ptr(w_p), bias=ptr(b_c), x_rows=ptr(ctx.x_rows),
+                          ld_rows=3 * Dp)
         check(_lib.lib().nr_conv1d_k3_bwd(C.byref(d), ptr(dy), ptr(dwp), ptr(db), _stream()), "nr_conv1d_k3_bwd")
         dw = torch.empty(N, D, 3, dtype=torch.float32, device=dev)
         check(_lib.lib().nr_unpack_conv_dw(ptr(dwp), N, D, Dp, ptr(dw), _stream()), "nr_unpack_conv_dw")

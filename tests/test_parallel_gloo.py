@@ -28,7 +28,9 @@ def _worker(rank, world, port, q):
         dp.allreduce_grads()
         opt.step()
     w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
-    q.put((rank, w0, w, x, y))
+    # plain lists, not tensors: a tensor travels as a file descriptor that the parent has to fetch from this process,
+    # which races with the worker's exit
+    q.put((rank, w0.tolist(), w.tolist(), x.tolist(), y.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -44,7 +46,7 @@ def test_flat_bucket_matches_single_process_mean_gradient():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, w0a, wa, xa, ya), (_, w0b, wb, xb, yb) = res
+    (_, w0a, wa, xa, ya), (_, w0b, wb, xb, yb) = [(r[0],) + tuple(torch.tensor(v) for v in r[1:]) for r in res]
     assert torch.equal(w0a, w0b)                        # rank-0 broadcast at construction
     assert torch.allclose(wa, wb, atol=0, rtol=0)       # identical parameters after 3 averaged steps
     # single-process replay: gradient = mean over the two shards' gradients
