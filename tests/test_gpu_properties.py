@@ -143,3 +143,58 @@ def test_empty_inputs_are_noops():
     out = ops.additive_pool(y, torch.randn(4, 8, device=DEV), torch.randn(4, device=DEV), torch.randn(1, 4, device=DEV),
                             torch.randn(1, device=DEV), code)
     assert out.shape == (0, 8)
+
+
+_SIDE_SCRIPT = r"""
+import json, sys, torch
+from types import SimpleNamespace
+from newsrecommendation_amd.model import NRMS
+torch.manual_seed(0)
+args = SimpleNamespace(num_words_title=30, user_log_length=50, npratio=4, word_embedding_dim=300, news_dim=400,
+                       num_attention_heads=20, news_query_vector_dim=200, user_query_vector_dim=200, drop_rate=0.2,
+                       user_log_mask=False, freeze_embedding=False, compute_dtype="bf16")
+g = torch.Generator().manual_seed(3)
+V, B = 5000, 64                                   # 64 * 55 * 30 = 105 600 token rows: above the fork threshold
+table = (torch.randn(V, 300, generator=g) * 0.4).numpy(); table[0] = 0
+m = NRMS.Model(args, table).cuda().train()
+hist = torch.randint(0, V, (B, 50, 30), generator=g, dtype=torch.int32).cuda()
+cand = torch.randint(0, V, (B, 5, 30), generator=g, dtype=torch.int32).cuda()
+mask = (torch.rand(B, 50, generator=g) < 0.8).float().cuda()
+label = torch.randint(0, 5, (B,), generator=g).cuda()
+torch.manual_seed(11)
+loss, score = m(hist, mask, cand, label)
+loss.backward()
+torch.cuda.synchronize()
+out = {"loss": float(loss)}
+for n, p in m.named_parameters():
+    if p.grad is not None:
+        out[n] = [float(p.grad.double().sum()), float(p.grad.double().abs().sum())]
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_side_stream_option_gives_the_same_gradients():
+    """NR_SIDE_STREAM=1 forks the input-gradient GEMMs of the MHSA / pooling backward onto a second stream
+    (fork/join by events).  Same seeds -> same dropout draws -> loss identical, gradient sums equal up to the
+    order of the fp32 atomics."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(side):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("NR_SIDE_STREAM", None)
+        if side:
+            env["NR_SIDE_STREAM"] = "1"
+        r = subprocess.run([sys.executable, "-c", _SIDE_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        return json.loads(line[7:])
+
+    a, b = run(False), run(True)
+    assert a["loss"] == b["loss"]
+    for k in a:
+        if k == "loss":
+            continue
+        (s0, a0), (s1, a1) = a[k], b[k]
+        assert abs(a0 - a1) <= 1e-4 * a0 + 1e-6, (k, a0, a1)
+        assert abs(s0 - s1) <= 1e-4 * a0 + 1e-6, (k, s0, s1)
