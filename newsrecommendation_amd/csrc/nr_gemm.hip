@@ -1257,10 +1257,12 @@ int launch_nt_dma_e(const RowSrc& A, const void* B, int ldb, int M, int N, int K
 namespace tn3 {
 using tn2::swz_a;
 using tn2::tr_frag;
-constexpr int TBN = 128, TBM = 32, NS = 4;
-template <int WK> struct Geo {
-  static constexpr int TBK = 80 * WK, NT = 128 * WK, NW = 2 * WK, CH = TBK / 8, SCW = TBK + 4;
-  static constexpr int PA = TBM * 16 / 64, PBP = TBM * CH / 64, NP = PA + PBP, STAGE = NP * 1024;
+constexpr int TBM = 32, NS = 4;
+// NI = 16-row A fragments per wave (2 n-waves): NI = 4 -> 128-row n-tile, NI = 8 -> 256-row n-tile (X is re-read
+// half as often and a wave runs 40 MFMAs per 13 fragment loads instead of 20 per 9: LDS traffic stops binding).
+template <int WK, int NI> struct Geo {
+  static constexpr int TBN = 32 * NI, TBK = 80 * WK, NT = 128 * WK, NW = 2 * WK, CHA = TBN / 8, CH = TBK / 8, SCW = TBK + 4;
+  static constexpr int PA = TBM * CHA / 64, PBP = TBM * CH / 64, NP = PA + PBP, STAGE = NP * 1024;
   static constexpr size_t RING = (size_t)NS * STAGE, EPI = (size_t)64 * SCW * sizeof(float);
   static constexpr size_t SMEM = RING > EPI ? RING : EPI;
 };
@@ -1270,13 +1272,14 @@ template <int WK> __device__ __forceinline__ int swz_b(int row, int chunk) {
   return WK == 2 ? chunk ^ (2 * ((row >> 3) & 1)) : chunk ^ (4 * ((row >> 1) & 1) + 2 * ((row >> 3) & 1));
 }
 
-template <int WK>
+template <int WK, int NI>
 __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __restrict__ dC, int ldc, const bf16_t* __restrict__ X,
                                                             int ldx, float* __restrict__ dW, int ldw, float* __restrict__ db,
                                                             int M, int N, int K, int Nstore, int Kstore, int tilesK, int ntile,
                                                             int nsplit, int rps) {
-  using G = Geo<WK>;
-  constexpr int TBK = G::TBK, NT = G::NT, NW = G::NW, CH = G::CH, SCW = G::SCW, PA = G::PA, NP = G::NP, STAGE = G::STAGE;
+  using G = Geo<WK, NI>;
+  constexpr int TBN = G::TBN, TBK = G::TBK, NT = G::NT, NW = G::NW, CHA = G::CHA, CH = G::CH, SCW = G::SCW, PA = G::PA, NP = G::NP,
+                STAGE = G::STAGE;
   constexpr int PB = NP / NW, PX = NP % NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sC = reinterpret_cast<float*>(smem);
@@ -1303,14 +1306,14 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
   for (int t = 0; t < PB + 1; ++t) {
     const int p = pfirst + t;
     if (p < PA) {
-      const int P = 64 * p + lane, row = P >> 4, cpos = P & 15;
+      const int P = 64 * p + lane, row = P / CHA, cpos = P - row * CHA;
       const int col = min(n0 + swz_a(row, cpos) * 8, N - 8);
       src[t] = dC + (size_t)(mbeg + row) * ldc + col;
       adv[t] = (size_t)TBM * ldc;
     } else {
-      const int P = 64 * (p - PA) + lane, row = P / CH, cpos = P - row * CH;
+      const int P = 64 * (p - PA) + lane, row = min(P / CH, TBM - 1), cpos = P - (P / CH) * CH;
       const int col = min(k0 + swz_b<WK>(row, cpos) * 8, K - 8);
-      src[t] = X + (size_t)(mbeg + min(row, TBM - 1)) * ldx + col;
+      src[t] = X + (size_t)(mbeg + row) * ldx + col;
       adv[t] = (size_t)TBM * ldx;
     }
   }
@@ -1331,25 +1334,21 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
     }
   };
 
-  f32x4 acc[4][5], accdb[4];
+  f32x4 acc[NI][5];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    accdb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 5; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
+  // db: ONE accumulator for all NI row tiles.  Tile i is multiplied by a selector matrix whose row i is all ones,
+  // so its column sums land in accumulator row i: accdb[row = tile][col = column inside the tile].
+  f32x4 accdb = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bf16_t one = (bf16_t)1.f, zero = (bf16_t)0.f;
 
   // transposed-read lane geometry (see tn2): 16-lane group g holds m rows 8g..8g+7
   const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
   const int r0 = 8 * g + q, r1 = r0 + 4, off = 4 * (pp & 1);
-  int oa0[4], oa1[4], ob0[5], ob1[5];               // element offsets inside a stage (loop invariant)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int chunk = (wm * 64 + i * 16) / 8 + (pp >> 1);
-    oa0[i] = r0 * TBN + swz_a(r0, chunk) * 8 + off;
-    oa1[i] = r1 * TBN + swz_a(r1, chunk) * 8 + off;
-  }
+  const int a0 = r0 * TBN + off, a1 = r1 * TBN + off, ca = wm * 2 * NI + (pp >> 1);   // A chunk of tile i: ca + 2i
+  int ob0[5], ob1[5];
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
     const int chunk = (wn * 80 + j * 16) / 8 + (pp >> 1);
@@ -1365,49 +1364,49 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
     __builtin_amdgcn_s_barrier();
     if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, kt + NS - 1);
     const bf16_t* st = reinterpret_cast<const bf16_t*>(smem + (kt % NS) * STAGE);
-    bf16x8 af[4], bf[5];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = tr_frag(st + oa0[i], st + oa1[i]);
+    bf16x8 bf[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) bf[j] = tr_frag(st + ob0[j], st + ob1[j]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i) {
+      const bf16x8 af = tr_frag(st + a0 + swz_a(r0, ca + 2 * i) * 8, st + a1 + swz_a(r1, ca + 2 * i) * 8);
 #pragma unroll
-      for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    if (db_wave) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) accdb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accdb[i], 0, 0, 0);
+      for (int j = 0; j < 5; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[j], acc[i][j], 0, 0, 0);
+      if (db_wave) {
+        const bf16_t v = (lane & 15) == i ? one : zero;
+        const bf16x8 sel = {v, v, v, v, v, v, v, v};
+        accdb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel, af, accdb, 0, 0, 0);
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  if (db_wave && (lane & 15) == 0) {                // every column of accdb holds the row sums
+  if (db_wave) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (n < Nstore) atomicAdd(db + n, accdb[i][r]);
-      }
+    for (int e = 0; e < 4; ++e) {
+      const int ti = 4 * (lane >> 4) + e, n = n0 + wm * 16 * NI + ti * 16 + (lane & 15);
+      if (ti < NI && n < Nstore) atomicAdd(db + n, accdb[e]);
+    }
   }
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if (half) __syncthreads();
-    if (wm == half) {
+  for (int pass = 0; pass < TBN / 64; ++pass) {
+    if (pass) __syncthreads();
+    if (wm == pass / (NI / 4)) {
+      const int ib = (pass % (NI / 4)) * 4;
 #pragma unroll
       for (int j = 0; j < 5; ++j) {
         const int col = wn * 80 + j * 16 + (lane & 15);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sC[(i * 16 + (lane >> 4) * 4 + r) * SCW + col] = acc[i][j][r];
+          for (int r = 0; r < 4; ++r) sC[(i * 16 + (lane >> 4) * 4 + r) * SCW + col] = acc[ib + i][j][r];
       }
     }
     __syncthreads();
     for (int u = tid; u < 64 * (TBK / 4); u += NT) {
       const int row = u / (TBK / 4), c0 = (u % (TBK / 4)) * 4;
-      const int n = n0 + half * 64 + row, k = k0 + c0;
+      const int n = n0 + pass * 64 + row, k = k0 + c0;
       if (n < Nstore && k < Kstore) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * SCW + c0);
         float* dst = dW + (size_t)n * ldw + k;
@@ -1419,21 +1418,24 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
   }
 }
 
-template <int WK>
+template <int WK, int NI>
 int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
              int Kstore, hipStream_t stream) {
-  using G = Geo<WK>;
-  const int tilesN = (N + TBN - 1) / TBN, tilesK = (K + G::TBK - 1) / G::TBK, ntile = tilesN * tilesK;
-  // whole rounds of resident workgroups (256 CUs x 1 or 2), splits a multiple of the 8 XCDs, >= 16 slabs per split
-  const int resident = 256 * (WK == 4 ? 1 : 2), rounds = WK == 4 ? 5 : 3;
-  int nsplit = ((resident * rounds / ntile + 4) / 8) * 8;
+  using G = Geo<WK, NI>;
+  const int tilesN = (N + G::TBN - 1) / G::TBN, tilesK = (K + G::TBK - 1) / G::TBK, ntile = tilesN * tilesK;
+  // ONE round of resident workgroups (256 CUs x 1 or 2), splits a multiple of the 8 XCDs, >= 16 slabs per split.
+  // Measured at N=1200, K=304: 1 / 2 / 3 / 4 rounds = 1.03 / 1.14 / 1.25 / 1.34 ms -- every split pays a ring fill and
+  // an fp32 atomic epilogue over the whole [N, K] tile, so fewer, longer splits win.
+  static const int force_rounds = [] { const char* e = getenv("NR_TN3_ROUNDS"); return e ? atoi(e) : 0; }();
+  const int resident = 256 * (WK == 4 ? 1 : 2), rounds = force_rounds ? force_rounds : 1;
+  int nsplit = (resident * rounds / ntile / 8) * 8;     // rounded down: never a few workgroups left for an extra round
   if (nsplit < 8) nsplit = 8;
   int rps = (M + nsplit - 1) / nsplit;
   rps = ((rps + TBM - 1) / TBM) * TBM;
   if (rps < 16 * TBM) rps = 16 * TBM;
   nsplit = (M + rps - 1) / rps;
   const int grid = ((nsplit + 7) / 8) * 8 * ntile;
-  auto kern = gemm_tn3_kernel<WK>;
+  auto kern = gemm_tn3_kernel<WK, NI>;
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::SMEM, stream, (const bf16_t*)dC, ldc, (const bf16_t*)X, ldx, dW, ldw, db, M, N,
                      K, Nstore, Kstore, tilesK, ntile, nsplit, rps);
@@ -1450,9 +1452,14 @@ bool eligible(int ldc, int ldx, int M, int N, int K) {
 int launch(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
            int Kstore, hipStream_t stream) {
   static const int force = [] { const char* e = getenv("NR_TN3_WK"); return e ? atoi(e) : 0; }();
+  static const int force_ni = [] { const char* e = getenv("NR_TN3_NI"); return e ? atoi(e) : 0; }();
   const bool wide = force ? force == 4 : (K > 160 && ((K + 319) / 320) * 320 * 100 <= K * 115);
-  if (wide) return launch_t<4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
-  return launch_t<2>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+  if (wide) {
+    const bool big = force_ni ? force_ni == 8 : N > 256;
+    if (big) return launch_t<4, 8>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+    return launch_t<4, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+  }
+  return launch_t<2, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
 }
 }  // namespace tn3
 

@@ -41,9 +41,10 @@ def test_gemm_nt_full_size_sampled_against_fp64_and_linearity():
     assert torch.equal(c2.float(), c.float() * 2)
 
 
-def test_gemm_tn_full_size_split_invariance_and_bias_grad():
+@pytest.mark.parametrize("N,K", [(200, 400), (1200, 304), (400, 960)])     # dW1, dW_qkv (256-row n-tile), conv dW (3 k-tiles)
+def test_gemm_tn_full_size_split_invariance_and_bias_grad(N, K):
     g = torch.Generator(device=DEV).manual_seed(1)
-    M, N, K = M_FULL, 200, 400
+    M = M_FULL
     dc = _bf(torch.randn(M, N, device=DEV, generator=g) * 0.05)
     a = _bf(torch.randn(M, K, device=DEV, generator=g) * 0.5)
     dw, db = ops.gemm_tn(dc, a)
@@ -55,7 +56,7 @@ def test_gemm_tn_full_size_split_invariance_and_bias_grad():
     assert (db - (db1 + db2)).abs().max().item() <= 1e-3 * db.abs().max().item() + 1e-3
     ref_db = dc.double().sum(0)
     assert (db.double() - ref_db).abs().max().item() <= 1e-3 * ref_db.abs().max().item() + 1e-2
-    cols = torch.arange(0, K, 37, device=DEV)
+    cols = torch.cat([torch.arange(0, K, 37, device=DEV), torch.tensor([K - 1], device=DEV)])
     ref = dc.double().t() @ a[:, cols].double()
     assert (dw[:, cols].double() - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-2
 
