@@ -747,16 +747,10 @@ __global__ __launch_bounds__(NTHR) void gemm_tn2_kernel(const bf16_t* __restrict
       }
     }
     __syncthreads();
-    for (int u = tid; u < 64 * (TBK / 4); u += NTHR) {
-      const int row = u / (TBK / 4), c0 = (u % (TBK / 4)) * 4;
-      const int n = n0 + half * 64 + row, k = k0 + c0;
-      if (n < Nstore && k < Kstore) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * SCW + c0);
-        float* dst = dW + (size_t)n * ldw + k;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k + e < Kstore) atomicAdd(dst + e, v[e]);
-      }
+    for (int u = tid; u < 64 * TBK; u += NTHR) {   // lanes on consecutive floats (whole lines per atomic instruction)
+      const int row = u / TBK, c = u - row * TBK;
+      const int n = n0 + half * 64 + row, k = k0 + c;
+      if (n < Nstore && k < Kstore) atomicAdd(dW + (size_t)n * ldw + k, sC[row * SCW + c]);
     }
   }
 }
@@ -1191,10 +1185,28 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
       }
     }
     __syncthreads();
-    for (int u = tid; u < 32 * (WBN / 4); u += WTHR) {
-      const int row = u / (WBN / 4), c0 = (u % (WBN / 4)) * 4;
-      const int m = m0 + pass * 32 + row;
-      if (m < M && c0 < N) emit4<EPI>(ep, m, nbase + c0, Ntot, *reinterpret_cast<const f32x4*>(sC + row * SCW + c0));
+    if (EPI == EPI_SCATTER) {
+      // table-gradient scatter: one wave per row, lanes on CONSECUTIVE floats, so an atomic instruction covers whole
+      // 128-byte lines of the destination row (float4-per-lane ownership spread every instruction over 8 lines)
+      for (int rr = wid; rr < 32; rr += NW) {
+        const int m = m0 + pass * 32 + rr;
+        if (m >= M) continue;
+        const int id = ep.ids[(size_t)m * ep.ids_stride];
+        if (id == 0) continue;                       // padding_idx row receives no gradient
+        float* dst = (float*)ep.C + (size_t)id * ep.ldc + nbase;
+        const uint32_t e0 = (uint32_t)m * (uint32_t)ep.Dtrue + (uint32_t)nbase;
+        for (int c = lane; c < N; c += 64) {
+          float x = sC[rr * SCW + c];
+          if (ep.drop.thresh) x = nr_keep(ep.drop.key, e0 + c, ep.drop.thresh) ? x * ep.drop.scale : 0.f;
+          if (x != 0.f && nbase + c < ep.Dtrue) atomicAdd(dst + c, x);
+        }
+      }
+    } else {
+      for (int u = tid; u < 32 * (WBN / 4); u += WTHR) {
+        const int row = u / (WBN / 4), c0 = (u % (WBN / 4)) * 4;
+        const int m = m0 + pass * 32 + row;
+        if (m < M && c0 < N) emit4<EPI>(ep, m, nbase + c0, Ntot, *reinterpret_cast<const f32x4*>(sC + row * SCW + c0));
+      }
     }
   }
 }
@@ -1404,16 +1416,11 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
       }
     }
     __syncthreads();
-    for (int u = tid; u < 64 * (TBK / 4); u += NT) {
-      const int row = u / (TBK / 4), c0 = (u % (TBK / 4)) * 4;
-      const int n = n0 + pass * 64 + row, k = k0 + c0;
-      if (n < Nstore && k < Kstore) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * SCW + c0);
-        float* dst = dW + (size_t)n * ldw + k;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (k + e < Kstore) atomicAdd(dst + e, v[e]);
-      }
+    // lanes on consecutive floats: one atomic instruction covers whole 128-byte lines of a dW row
+    for (int u = tid; u < 64 * TBK; u += NT) {
+      const int row = u / TBK, c = u - row * TBK;
+      const int n = n0 + pass * 64 + row, k = k0 + c;
+      if (n < Nstore && k < Kstore) atomicAdd(dW + (size_t)n * ldw + k, sC[row * SCW + c]);
     }
   }
 }
