@@ -1018,6 +1018,22 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
   // B tile row (wn*HN + j)*16 + fr : + j*1024 per column tile (16 rows x 64 B; the swizzle has period 16 rows)
   const int offB = AB + wn * HN * 1024 + fr * 64 + ((g ^ swzP(fr)) << 4);
 
+  // POOLBWD: the pooled-gradient rows g[title] and alpha of this tile are DMA'd into LDS behind the ring before the
+  // main loop starts (they are the oldest loads, so every later counted wait covers them); the epilogue then reads them
+  // from LDS instead of issuing ~30 dependent global loads per lane with nothing left to hide their latency.
+  constexpr int GT = 12, GBYTES = ((GT * WBN * 4 + 1023) / 1024) * 1024;        // up to 12 titles per tile (L >= 24)
+  const bool g_lds = (EPI == EPI_POOLBWD) && PK && ep.L >= DBM / (GT - 2) && (ep.ldg % 4 == 0) && (nbase % 4 == 0) &&
+                     (((uintptr_t)ep.G & 15) == 0) && (((uintptr_t)ep.rowscale & 15) == 0) && M >= 4;
+  const int t0 = (EPI == EPI_POOLBWD) ? m0 / max(ep.L, 1) : 0;
+  if (g_lds) {
+    const int tlast = (M - 1) / ep.L;
+    for (int p = wid; p < GBYTES / 1024; p += NW) {
+      const int u = 64 * p + lane, t = u / (WBN / 4), c4 = u - t * (WBN / 4);
+      const float* gsrc = ep.G + (size_t)min(t0 + t, tlast) * ep.ldg + nbase + min(4 * c4, max(N - 4, 0));
+      dma16(gsrc, lds0 + NS * STAGE + p * 1024);
+    }
+    if (wid == NW - 1) dma16(ep.rowscale + min(m0 + 4 * lane, M - 4), lds0 + NS * STAGE + GBYTES);   // alpha of rows m0 .. m0+255
+  }
   const int nk = (K + BK - 1) / BK;
 #pragma unroll
   for (int s = 0; s < NS - 1; ++s)
@@ -1112,6 +1128,22 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
     for (int pass = 0; pass < WM / 2; ++pass) {
       if (pass) __syncthreads();
       if ((wm >> 1) == pass) {
+        // POOLBWD: the lane's 4 rows, their alpha and pooled-gradient rows, looked up once (not per column tile)
+        float rs4[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* grow4[4] = {nullptr, nullptr, nullptr, nullptr};
+        const float* sG = reinterpret_cast<const float*>(smem + NS * STAGE);
+        const float* sAl = reinterpret_cast<const float*>(smem + NS * STAGE + GBYTES);
+        if (EPI == EPI_POOLBWD) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int mloc = pass * 128 + (wm & 1) * 64 + i * 16 + (lane & 15), m = m0 + mloc;
+            if (m < M) {
+              if (g_lds && m0 + 255 < M) rs4[i] = sAl[mloc]; else rs4[i] = ep.rowscale[m];
+              grow4[i] = g_lds ? sG + (m / ep.L - t0) * WBN : ep.G + (size_t)(m / ep.L) * ep.ldg + nbase;
+            }
+          }
+        }
+        const bool gvec = g_lds || ((EPI == EPI_POOLBWD) && (ep.ldg % 4 == 0) && (nbase % 4 == 0) && (((uintptr_t)ep.G & 15) == 0));
 #pragma unroll
         for (int j = 0; j < HN; ++j) {
           const int jt = wn * HN + j;
@@ -1131,12 +1163,16 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
               }
-              if (EPI == EPI_POOLBWD && m < M) {
-                const float rs = ep.rowscale[m];
-                const float* grow = ep.G + (size_t)(m / ep.L) * ep.ldg + nbase;
+              if (EPI == EPI_POOLBWD && grow4[i] != nullptr) {
+                if (gvec && nl + 4 <= N) {
+                  const f32x4 gq = *reinterpret_cast<const f32x4*>(grow4[i] + nl);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  if (nl + r < N) v[r] += rs * grow[nl + r];
+                  for (int r = 0; r < 4; ++r) v[r] += rs4[i] * gq[r];
+                } else {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    if (nl + r < N) v[r] += rs4[i] * grow4[i][nl + r];
+                }
               }
               const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
               *reinterpret_cast<bf16x4*>(sCb + ml * SCB + nl) = o;
@@ -1216,7 +1252,8 @@ int launch_nt_dma_w(const RowSrc& A, const void* B, int ldb, int M, int N, int K
   constexpr int DBM = 64 * WM, NP = DBM / 16 + NT16, STAGE = NP * 1024, NS = dma_ring_stages(STAGE, WM);
   constexpr size_t ring = (size_t)NS * STAGE, epi = (size_t)32 * (NT16 * 16 + 4) * sizeof(float);
   constexpr size_t epk = PK ? (size_t)128 * (NT16 * 16 + 8) * sizeof(bf16_t) : 0;
-  constexpr size_t smem0 = ring > epi ? ring : epi, smem = smem0 > epk ? smem0 : epk;
+  constexpr size_t gtile = (EPI == EPI_POOLBWD && PK) ? (size_t)((12 * NT16 * 16 * 4 + 1023) / 1024) * 1024 + 1024 : 0;
+  constexpr size_t smem0 = ring > epi ? ring : epi, smem1 = smem0 > epk ? smem0 : epk, smem = smem1 + gtile;
   auto kern = gemm_nt_dma_kernel<EPI, NT16, PK, WM>;
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   const int tilesM = (M + DBM - 1) / DBM, nchunks = (N + NT16 * 16 - 1) / (NT16 * 16);
@@ -1233,7 +1270,8 @@ int launch_nt_dma_p(const RowSrc& A, const void* B, int ldb, int M, int N, int K
   // column chunk (att_fc1: 0.47 -> 0.41 ms); with several chunks the smaller tile re-reads A more often and loses
   // (QKV projection: 1.45 -> 1.57 ms)
   constexpr bool fits2 = 3 * (8 + NT16) * 1024 <= 78 * 1024;
-  if (fits2 && N <= NT16 * 16) return launch_nt_dma_w<EPI, NT16, PK, 2>(A, B, ldb, M, N, K, ep, stream);
+  static const bool wm2_all = getenv("NR_DMA_WM2_ALL") != nullptr;
+  if (fits2 && (N <= NT16 * 16 || wm2_all)) return launch_nt_dma_w<EPI, NT16, PK, 2>(A, B, ldb, M, N, K, ep, stream);
   return launch_nt_dma_w<EPI, NT16, PK, 4>(A, B, ldb, M, N, K, ep, stream);
 }
 
@@ -1580,7 +1618,7 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
   static const bool no_dma = getenv("NR_NT_NODMA") != nullptr;
   const int kr32 = (K + 31) / 32 * 32;
   const bool dense_bf16 = dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0 && ep.rows_out == nullptr;
-  static const int dma_min_k = getenv("NR_DMA_MIN_K") ? atoi(getenv("NR_DMA_MIN_K")) : 256;
+  static const int dma_min_k = getenv("NR_DMA_MIN_K") ? atoi(getenv("NR_DMA_MIN_K")) : 192;
   if (dense_bf16 && !no_dma && K >= dma_min_k && ldb >= kr32 && A.ld >= K) {
     // B must be zero beyond K up to the next multiple of 32 (nr_cast_pad with such an ld guarantees it)
     NrProfScope ps(stream, "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d]", epi, M, N, K);
