@@ -1025,6 +1025,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
   const bool g_lds = (EPI == EPI_POOLBWD) && PK && ep.L >= DBM / (GT - 2) && (ep.ldg % 4 == 0) && (nbase % 4 == 0) &&
                      (((uintptr_t)ep.G & 15) == 0) && (((uintptr_t)ep.rowscale & 15) == 0) && M >= 4;
   const int t0 = (EPI == EPI_POOLBWD) ? m0 / max(ep.L, 1) : 0;
+  // STORE / STORE_TANH: the bias of this column chunk, same idea (one DMA piece)
+  const bool b_lds = (EPI == EPI_STORE || EPI == EPI_STORE_TANH) && PK && ep.bias != nullptr && (nbase % 4 == 0) && N >= 4 &&
+                     (((uintptr_t)ep.bias & 15) == 0);
+  if (b_lds && wid == NW - 1) dma16(ep.bias + nbase + min(4 * lane, ((N - 4) / 4) * 4), lds0 + NS * STAGE);
+  // SCATTER: the 256 token ids of this tile
+  const bool i_lds = (EPI == EPI_SCATTER) && !PK && ep.ids_stride == 1 && M >= 4 && (((uintptr_t)ep.ids & 15) == 0);
+  if (i_lds && wid == NW - 1) dma16(ep.ids + min(m0 + 4 * lane, M - 4), lds0 + NS * STAGE);
   if (g_lds) {
     const int tlast = (M - 1) / ep.L;
     for (int p = wid; p < GBYTES / 1024; p += NW) {
@@ -1151,9 +1158,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
             const int nl = jt * 16 + 4 * (lane >> 4);
             f32x4 bvec = (f32x4){0.f, 0.f, 0.f, 0.f};
             if ((EPI == EPI_STORE || EPI == EPI_STORE_TANH) && ep.bias != nullptr) {
+              if (b_lds && nl + 4 <= N) {
+                bvec = *reinterpret_cast<const f32x4*>(sG + nl);
+              } else {
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (nl + r < N) bvec[r] = ep.bias[nbase + nl + r];
+                for (int r = 0; r < 4; ++r)
+                  if (nl + r < N) bvec[r] = ep.bias[nbase + nl + r];
+              }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1227,7 +1238,8 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
       for (int rr = wid; rr < 32; rr += NW) {
         const int m = m0 + pass * 32 + rr;
         if (m >= M) continue;
-        const int id = ep.ids[(size_t)m * ep.ids_stride];
+        const int mloc = pass * 32 + rr;
+        const int id = (i_lds && m0 + 255 < M) ? reinterpret_cast<const int*>(smem + NS * STAGE)[mloc] : ep.ids[(size_t)m * ep.ids_stride];
         if (id == 0) continue;                       // padding_idx row receives no gradient
         float* dst = (float*)ep.C + (size_t)id * ep.ldc + nbase;
         const uint32_t e0 = (uint32_t)m * (uint32_t)ep.Dtrue + (uint32_t)nbase;
@@ -1252,7 +1264,7 @@ int launch_nt_dma_w(const RowSrc& A, const void* B, int ldb, int M, int N, int K
   constexpr int DBM = 64 * WM, NP = DBM / 16 + NT16, STAGE = NP * 1024, NS = dma_ring_stages(STAGE, WM);
   constexpr size_t ring = (size_t)NS * STAGE, epi = (size_t)32 * (NT16 * 16 + 4) * sizeof(float);
   constexpr size_t epk = PK ? (size_t)128 * (NT16 * 16 + 8) * sizeof(bf16_t) : 0;
-  constexpr size_t gtile = (EPI == EPI_POOLBWD && PK) ? (size_t)((12 * NT16 * 16 * 4 + 1023) / 1024) * 1024 + 1024 : 0;
+  constexpr size_t gtile = EPI == EPI_POOLBWD && PK ? (size_t)((12 * NT16 * 16 * 4 + 1023) / 1024) * 1024 + 1024 : 1024;
   constexpr size_t smem0 = ring > epi ? ring : epi, smem1 = smem0 > epk ? smem0 : epk, smem = smem1 + gtile;
   auto kern = gemm_nt_dma_kernel<EPI, NT16, PK, WM>;
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
