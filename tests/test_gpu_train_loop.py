@@ -100,3 +100,45 @@ def test_train_loop_tracks_oracle_and_eval_matches(tmp_path):
         cnt += 1
     assert cnt > 50
     assert np.allclose(means, sums / cnt, atol=1e-9), (means, sums / cnt)
+
+
+def test_ddp_wrapper_over_rccl_gives_the_plain_gradients():
+    """main.py:82 wraps the model in DistributedDataParallel.  One rank over the 'nccl' (= RCCL) backend: the reducer's
+    hooks, bucket views and the rank-0 broadcast run against the package's autograd Functions, and with a single rank
+    the averaged gradients must equal the plain ones (same seeds -> same dropout draws)."""
+    import torch.distributed as dist
+    from newsrecommendation_amd.model import NRMS
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        args = SimpleNamespace(num_words_title=30, user_log_length=50, npratio=4, word_embedding_dim=300, news_dim=400,
+                               num_attention_heads=20, news_query_vector_dim=200, user_query_vector_dim=200, drop_rate=0.2,
+                               user_log_mask=False, freeze_embedding=False, compute_dtype="bf16")
+        g = torch.Generator().manual_seed(3)
+        V, B = 2000, 8
+        table = (torch.randn(V, 300, generator=g) * 0.4).numpy()
+        table[0] = 0
+        hist = torch.randint(0, V, (B, 50, 30), generator=g, dtype=torch.int32).cuda()
+        cand = torch.randint(0, V, (B, 5, 30), generator=g, dtype=torch.int32).cuda()
+        mask = (torch.rand(B, 50, generator=g) < 0.8).float().cuda()
+        label = torch.randint(0, 5, (B,), generator=g).cuda()
+
+        def grads(wrap):
+            torch.manual_seed(0)
+            m = NRMS.Model(args, table).cuda().train()
+            net = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0]) if wrap else m
+            torch.manual_seed(11)
+            loss, _ = net(hist, mask, cand, label)
+            loss.backward()
+            torch.cuda.synchronize()
+            return float(loss), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+        l0, g0 = grads(False)
+        l1, g1 = grads(True)
+        assert l0 == l1
+        assert g0.keys() == g1.keys() and len(g0) >= 10
+        for k in g0:
+            tol = 1e-5 * float(g0[k].abs().max()) + 1e-7      # order of the fp32 atomics only
+            assert float((g0[k] - g1[k]).abs().max()) <= tol, k
+    finally:
+        dist.destroy_process_group()
