@@ -50,7 +50,8 @@ def train(rank, args, news_index, news_combined, embedding_matrix, category_dict
     if getattr(args, "load_ckpt_name", None):
         ckpt = torch.load(os.path.join(args.model_dir, args.load_ckpt_name), map_location="cpu", weights_only=True)
         model.load_state_dict(ckpt["model_state_dict"])
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)       # main.py:76
+    # main.py:76; on the GPU the fused implementation (same update rule, one kernel) replaces the foreach one
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr, fused=next(model.parameters()).is_cuda)
     model = model.to(device)
     net = model
     if is_distributed:
