@@ -77,9 +77,20 @@ class Model(torch.nn.Module):
         cand = candidate.reshape(-1, a.num_words_title)
         hist = history.reshape(-1, a.num_words_title)
         # one encoder pass over candidates + history (the reference makes two, src/model/NRMS.py:87,90)
-        vecs = self.news_encoder(torch.cat([cand, hist], dim=0))
+        if getattr(a, "compact_history", False):
+            # Opt-in, beyond the reference: a history slot with mask 0 reaches the loss only through `vec * 0` (pad_doc
+            # blend, NRMS.py:59-60) or through attention / pooling weights that the mask zeroes (model_utils.py:28,51),
+            # so its news vector and every gradient through it are exactly 0 -- the reference encodes those titles for
+            # nothing.  Encode only the live slots and scatter them back.  Same loss / score / gradients in eval mode;
+            # in training the dropout draws land on different rows (the counters follow the compacted order).
+            live = (history_mask.reshape(-1) != 0).nonzero(as_tuple=False).squeeze(1)     # host sync: the count
+            vecs = self.news_encoder(torch.cat([cand, hist.index_select(0, live)], dim=0))
+            hist_flat = vecs.new_zeros(hist.shape[0], a.news_dim).index_copy(0, live, vecs[B * C:])
+        else:
+            vecs = self.news_encoder(torch.cat([cand, hist], dim=0))
+            hist_flat = vecs[B * C:]
         cand_vecs = vecs[: B * C].reshape(B, C, a.news_dim)
-        hist_vecs = vecs[B * C:].reshape(B, a.user_log_length, a.news_dim)
+        hist_vecs = hist_flat.reshape(B, a.user_log_length, a.news_dim)
         user_vec = self.user_encoder(hist_vecs, history_mask)
         loss, score = ops.score_ce(cand_vecs, user_vec, label)
         return loss, score

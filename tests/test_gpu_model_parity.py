@@ -91,3 +91,25 @@ def test_state_dict_surface():
         assert list(ours.keys()) == list(sd.keys())
         for k in sd:
             assert tuple(ours[k].shape) == tuple(sd[k].shape), k
+
+
+@pytest.mark.parametrize("tag", ["nrms_mind_pad", "nrms_mind_mask"])
+def test_compact_history_option_changes_nothing_observable(tag):
+    """args.compact_history encodes only history slots with mask != 0 (the others reach the loss through a factor 0).
+    Eval mode (no dropout): loss, score and every gradient equal the full computation's up to the order of atomics."""
+    from helpers import build_model, batch_of
+    outs = []
+    for compact in (False, True):
+        m, z, cfg, sd = build_model(tag, "fp32", train=False)
+        m.args.compact_history = compact
+        hist, mask, cand, label = batch_of(z)
+        assert float((mask == 0).sum()) > 0                      # the case has dead slots
+        loss, score = m(hist, mask, cand, label)
+        loss.backward()
+        outs.append((loss.detach(), score.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    (l0, s0, g0), (l1, s1, g1) = outs
+    assert abs(float(l0) - float(l1)) <= 1e-6
+    assert float((s0 - s1).abs().max()) <= 1e-6
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * float(g0[k].abs().max()) + 1e-8, k
