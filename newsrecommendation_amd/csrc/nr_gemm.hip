@@ -971,6 +971,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
   const int N = min(WBN, Ntot - nbase);
   constexpr int HN = (NT16 + 1) / 2;             // column tiles per wave
   const int tid = threadIdx.x, lane = tid & 63;
+  if (EPI == EPI_SCATTER) {
+    // A tile whose token ids are all 0 (padding: zero-padded title tails, empty history slots) scatters nothing
+    // (padding_idx row, src/model/NRMS.py:71): leave before loading anything.  ~30 % of the tiles of a MIND-shaped batch.
+    bool live = false;
+    for (int r = tid; r < DBM && m0 + r < M; r += WTHR) live |= ep.ids[(size_t)(m0 + r) * ep.ids_stride] != 0;
+    if (!__syncthreads_or(live)) return;
+  }
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
   const bool extra = wid < PX;                   // wave-uniform
   const int pfirst = wid * PB + min(wid, PX);    // first piece of this wave
