@@ -102,6 +102,9 @@ typedef struct {
                          them back as a dense operand of the weight-gradient GEMM (no second gather / RNG pass);
                          NULL: backward regenerates X from (table, ids, seed_in).                            */
   int ld_rows;
+  int32_t* row_ws;    /* optional backward scratch, int32 [2*n*L + 4] (gather source only): nr_mhsa_bwd compacts the rows
+                         whose token id is not the padding id 0 -- the only rows that add to the table gradient -- and
+                         runs the dX GEMM over those alone.  NULL: every row goes through the GEMM.            */
 } nr_mhsa_desc;
 
 /* qkv: [n*L, 3N] dtype (saved for backward); y: [n*L, N] dtype.

@@ -293,6 +293,11 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
       NR_CHECK_ARG(d->d_model % 4 == 0, "mhsa_bwd: d_model=%d must be a multiple of 4", d->d_model);
       EpiArgs ep = store_epi(dtable, d->d_model, NR_F32, nullptr, 0);
       ep.ids = d->ids; ep.ids_stride = 1; ep.Dtrue = d->d_model; ep.drop = nr_make_drop(d->p_in, d->seed_in);
+      if (d->row_ws != nullptr && d->dtype == NR_BF16 && M >= 4096) {
+        // only rows with a non-padding token id reach the table gradient: compact them, GEMM over those alone
+        if ((rc = nr_launch_compact_rows(d->ids, 1, M, d->row_ws, s))) return rc;
+        ep.row_count = d->row_ws; ep.row_idx = d->row_ws + 4; ep.row_ids = d->row_ws + 4 + M;
+      }
       rc = nr_launch_gemm_nt(d->dtype, G, w_qkv_t, ldwt, M, d->d_model, 3 * N, EPI_SCATTER, ep, s);
     } else {
       NR_CHECK_ARG(dx != nullptr && dtable == nullptr, "mhsa_bwd: dense source takes dx, not dtable");

@@ -40,6 +40,9 @@ struct EpiArgs {
   int ids_stride;
   int Dtrue;
   DropCfg drop;           // SCATTER: the forward's input dropout
+  const int32_t* row_count;  // SCATTER, optional compaction (nr_launch_compact_rows): device count of live rows,
+  const int32_t* row_idx;    //   their original row numbers (A row, dropout element index) and
+  const int32_t* row_ids;    //   their token ids, both in compacted order
   void* rows_out;         // optional: the staged A rows (after gather / dropout), dtype, [M, ld_rows_out]
   int ld_rows_out;
 };
@@ -48,5 +51,7 @@ struct EpiArgs {
 int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi,
                       const EpiArgs& ep, hipStream_t stream);
 int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, int M, int K, hipStream_t stream);
+// ws: int32 [2*M + 4] -> ws[0] = number of rows with ids[m*stride] != 0, ws[4 ..] their row numbers, ws[4 + M ..] their ids
+int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* ws, hipStream_t stream);
 int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db,
                       int M, int N, int K, int Nstore, int Kstore, hipStream_t stream);

@@ -971,7 +971,11 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
   const int N = min(WBN, Ntot - nbase);
   constexpr int HN = (NT16 + 1) / 2;             // column tiles per wave
   const int tid = threadIdx.x, lane = tid & 63;
-  if (EPI == EPI_SCATTER) {
+  const bool compact = (EPI == EPI_SCATTER) && ep.row_count != nullptr;
+  if (compact) {
+    M = *ep.row_count;                             // rows that survive the compaction (device side, no host sync)
+    if (m0 >= M) return;
+  } else if (EPI == EPI_SCATTER) {
     // A tile whose token ids are all 0 (padding: zero-padded title tails, empty history slots) scatters nothing
     // (padding_idx row, src/model/NRMS.py:71): leave before loading anything.  ~30 % of the tiles of a MIND-shaped batch.
     bool live = false;
@@ -990,7 +994,9 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
   for (int t = 0; t < PB + 1; ++t) {
     const int p = pfirst + t;
     if (p < DBM / 16) {
-      src[t] = A + (size_t)min(m0 + 16 * p + prow, M - 1) * lda + c8;
+      int arow = min(m0 + 16 * p + prow, M - 1);
+      if (compact) arow = ep.row_idx[arow];        // compacted row -> row of A
+      src[t] = A + (size_t)arow * lda + c8;
       isA[t] = true;
     } else {
       src[t] = B + (size_t)min(nbase + 16 * (p - DBM / 16) + prow, Ntot - 1) * ldb + c8;
@@ -1037,8 +1043,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
                      (((uintptr_t)ep.bias & 15) == 0);
   if (b_lds && wid == NW - 1) dma16(ep.bias + nbase + min(4 * lane, ((N - 4) / 4) * 4), lds0 + NS * STAGE);
   // SCATTER: the 256 token ids of this tile
-  const bool i_lds = (EPI == EPI_SCATTER) && !PK && ep.ids_stride == 1 && M >= 4 && (((uintptr_t)ep.ids & 15) == 0);
-  if (i_lds && wid == NW - 1) dma16(ep.ids + min(m0 + 4 * lane, M - 4), lds0 + NS * STAGE);
+  const int32_t* tile_ids = compact ? ep.row_ids : ep.ids;
+  const bool i_lds = (EPI == EPI_SCATTER) && !PK && (compact || ep.ids_stride == 1) && M >= 4 && (((uintptr_t)tile_ids & 15) == 0) &&
+                     (!compact || (((uintptr_t)ep.row_idx & 15) == 0));
+  if (i_lds && wid == NW - 1) {
+    dma16(tile_ids + min(m0 + 4 * lane, M - 4), lds0 + NS * STAGE);
+    if (compact) dma16(ep.row_idx + min(m0 + 4 * lane, M - 4), lds0 + NS * STAGE + 1024);
+  }
   if (g_lds) {
     const int tlast = (M - 1) / ep.L;
     for (int p = wid; p < GBYTES / 1024; p += NW) {
@@ -1246,10 +1257,14 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
         const int m = m0 + pass * 32 + rr;
         if (m >= M) continue;
         const int mloc = pass * 32 + rr;
-        const int id = (i_lds && m0 + 255 < M) ? reinterpret_cast<const int*>(smem + NS * STAGE)[mloc] : ep.ids[(size_t)m * ep.ids_stride];
+        const bool from_lds = i_lds && m0 + 255 < M;
+        const int id = from_lds ? reinterpret_cast<const int*>(smem + NS * STAGE)[mloc]
+                                : (compact ? ep.row_ids[m] : ep.ids[(size_t)m * ep.ids_stride]);
         if (id == 0) continue;                       // padding_idx row receives no gradient
         float* dst = (float*)ep.C + (size_t)id * ep.ldc + nbase;
-        const uint32_t e0 = (uint32_t)m * (uint32_t)ep.Dtrue + (uint32_t)nbase;
+        // the dropout counter follows the ORIGINAL row
+        const int morig = !compact ? m : (from_lds ? reinterpret_cast<const int*>(smem + NS * STAGE + 1024)[mloc] : ep.row_idx[m]);
+        const uint32_t e0 = (uint32_t)morig * (uint32_t)ep.Dtrue + (uint32_t)nbase;
         for (int c = lane; c < N; c += 64) {
           float x = sC[rr * SCW + c];
           if (ep.drop.thresh) x = nr_keep(ep.drop.key, e0 + c, ep.drop.thresh) ? x * ep.drop.scale : 0.f;
@@ -1271,7 +1286,8 @@ int launch_nt_dma_w(const RowSrc& A, const void* B, int ldb, int M, int N, int K
   constexpr int DBM = 64 * WM, NP = DBM / 16 + NT16, STAGE = NP * 1024, NS = dma_ring_stages(STAGE, WM);
   constexpr size_t ring = (size_t)NS * STAGE, epi = (size_t)32 * (NT16 * 16 + 4) * sizeof(float);
   constexpr size_t epk = PK ? (size_t)128 * (NT16 * 16 + 8) * sizeof(bf16_t) : 0;
-  constexpr size_t gtile = EPI == EPI_POOLBWD && PK ? (size_t)((12 * NT16 * 16 * 4 + 1023) / 1024) * 1024 + 1024 : 1024;
+  constexpr size_t gtile = EPI == EPI_POOLBWD && PK ? (size_t)((12 * NT16 * 16 * 4 + 1023) / 1024) * 1024 + 1024
+                                                    : (EPI == EPI_SCATTER ? 2048 : 1024);
   constexpr size_t smem0 = ring > epi ? ring : epi, smem1 = smem0 > epk ? smem0 : epk, smem = smem1 + gtile;
   auto kern = gemm_nt_dma_kernel<EPI, NT16, PK, WM>;
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1599,6 +1615,39 @@ int launch_tn_d(const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, fl
 }
 
 }  // namespace
+
+// Row compaction for the table-gradient GEMM: rows with token id 0 add nothing (padding_idx), and in a MIND-shaped
+// batch they are ~70 % of all rows (zero-padded title tails, empty history slots).  One pass, no host round trip:
+// 256 rows per workgroup, order kept inside a workgroup, workgroups append through one atomic counter.
+namespace {
+__global__ __launch_bounds__(256) void compact_rows_kernel(const int32_t* __restrict__ ids, int stride, int M, int32_t* __restrict__ ws) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int m = blockIdx.x * 256 + tid;
+  const int id = m < M ? ids[(size_t)m * stride] : 0;
+  const uint64_t bal = __ballot(id != 0);
+  if (lane == 0) wave_cnt[wid] = __popcll(bal);
+  __syncthreads();
+  if (tid == 0) base = atomicAdd(ws, wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+  __syncthreads();
+  if (id != 0) {
+    int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wid; ++w) pos += wave_cnt[w];
+    ws[4 + pos] = m;
+    ws[4 + M + pos] = id;
+  }
+}
+}  // namespace
+
+int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* ws, hipStream_t stream) {
+  NR_CHECK_ARG(ids != nullptr && ws != nullptr && M > 0 && ids_stride >= 1, "compact_rows: bad arguments");
+  NR_CHECK_HIP(hipMemsetAsync(ws, 0, 4 * sizeof(int32_t), stream));
+  NrProfScope ps(stream, "compact_rows[M=%d]", M);
+  hipLaunchKernelGGL(compact_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, ids, ids_stride, M, ws);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
 
 int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, int M, int K, hipStream_t stream) {
   const int ch = nr_chunk(dtype);

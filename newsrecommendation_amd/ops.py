@@ -154,18 +154,19 @@ class MHSAFunction(Function):
         dw = torch.zeros(3 * N, d_model, dtype=torch.float32, device=dev)
         db = torch.zeros(3 * N, dtype=torch.float32, device=dev)
         need_x = ctx.needs_input_grad[0]
-        dx = dtable = w_t = None
+        dx = dtable = w_t = row_ws = None
         if need_x:
             w_t = pack(wcat, code, transpose=True)                     # [d_model, 3N]
             if gather:
                 dtable = torch.zeros(cfg["table_shape"], dtype=torch.float32, device=dev)
+                row_ws = torch.empty(2 * n * L + 4, dtype=torch.int32, device=dev)     # live-row compaction scratch
             else:
                 dx = torch.empty(n, L, ldx, dtype=torch_dtype(code), device=dev)
         d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=d_head, dtype=code,
                           src_kind=NR_SRC_GATHER if gather else NR_SRC_DENSE, x=ptr(src), ldx=ldx, ids=ptr(ids),
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
-                          x_rows=ptr(x_rows), ld_rows=x_rows.shape[1] if x_rows is not None else 0)
+                          x_rows=ptr(x_rows), ld_rows=x_rows.shape[1] if x_rows is not None else 0, row_ws=ptr(row_ws))
         check(_lib.lib().nr_mhsa_bwd(C.byref(d), ptr(qkv), ptr(dy), ptr(dqkv), ptr(w_t), w_t.shape[1] if w_t is not None else 0,
                                      ptr(dw), ptr(db), ptr(dx), ptr(dtable), _stream()), "nr_mhsa_bwd")
         gx = dtable if gather else dx
