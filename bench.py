@@ -123,7 +123,7 @@ def roofline_of(prof, dtype):
     label, (cnt, ms) = max(prof.items(), key=lambda kv: kv[1][1])
     avg_s = ms / cnt / 1e3
     esz = 2 if dtype == "bf16" else 4
-    if label.startswith("gemm"):
+    if label.startswith("gemm") and "_live[" not in label:      # "_live": row count known on the device only
         fl = gemm_flops(label)
         peak = PEAK_MFMA_BF16 if "bf16" in label else PEAK_MFMA_F32
         ach = fl / avg_s / 1e12

@@ -102,9 +102,12 @@ typedef struct {
                          them back as a dense operand of the weight-gradient GEMM (no second gather / RNG pass);
                          NULL: backward regenerates X from (table, ids, seed_in).                            */
   int ld_rows;
-  int32_t* row_ws;    /* optional backward scratch, int32 [2*n*L + 4] (gather source only): nr_mhsa_bwd compacts the rows
-                         whose token id is not the padding id 0 -- the only rows that add to the table gradient -- and
-                         runs the dX GEMM over those alone.  NULL: every row goes through the GEMM.            */
+  int32_t* row_ws;    /* optional scratch, int32 [3*n*L + 4] (bf16 gather source only).  Padding tokens (id 0) gather the
+                         zero row of the table: nr_mhsa_fwd (when x_rows is given too) compacts the other rows on the
+                         device, projects those alone and writes the bias into the rest (if table row 0 is not zero every
+                         row is kept); nr_mhsa_bwd compacts again and runs the dX GEMM over the rows that reach the
+                         table gradient.  No host synchronisation.  NULL: every row goes through the GEMMs.       */
+  int row_ws_ready;   /* nr_mhsa_bwd only: nonzero = row_ws still holds what nr_mhsa_fwd wrote for these ids (reused as is) */
 } nr_mhsa_desc;
 
 /* qkv: [n*L, 3N] dtype (saved for backward); y: [n*L, N] dtype.

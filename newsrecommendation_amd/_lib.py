@@ -27,7 +27,7 @@ class MhsaDesc(C.Structure):
                 ("dtype", C.c_int), ("src_kind", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int), ("ids", C.c_void_p),
                 ("p_in", C.c_float), ("seed_in", C.c_uint32), ("p_out", C.c_float), ("seed_out", C.c_uint32),
                 ("mask", C.c_void_p), ("w_qkv", C.c_void_p), ("ldw", C.c_int), ("b_qkv", C.c_void_p),
-                ("x_rows", C.c_void_p), ("ld_rows", C.c_int), ("row_ws", C.c_void_p)]
+                ("x_rows", C.c_void_p), ("ld_rows", C.c_int), ("row_ws", C.c_void_p), ("row_ws_ready", C.c_int)]
 
 
 class ConvDesc(C.Structure):

@@ -254,6 +254,14 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
     NR_CHECK_ARG(d->ld_rows >= Kp && d->ld_rows % nr_chunk(d->dtype) == 0, "mhsa_fwd: ld_rows=%d must cover %d", d->ld_rows, Kp);
     if ((rc = nr_launch_rows_materialize(d->dtype, A, d->x_rows, d->ld_rows, M, Kp, s))) return rc;
     A = dense_rows(d->x_rows, d->ld_rows, d->d_model);
+    if (d->row_ws != nullptr && d->dtype == NR_BF16 && M >= 4096 && (3 * N) % 8 == 0) {
+      // Padding tokens (id 0) gather the zero row of the table: their projection is the bias.  Project the live rows
+      // only (compacted on the device) and write the bias into the others.  If table row 0 is not zero, the
+      // compaction keeps every row and nothing changes.
+      if ((rc = nr_launch_compact_rows_fwd(d->ids, M, d->x, d->d_model, d->row_ws, s))) return rc;
+      if ((rc = nr_launch_bias_rows(qkv, 3 * N, 3 * N, d->b_qkv, d->row_ws + 4 + 2 * (size_t)M, d->row_ws + 1, M, s))) return rc;
+      ep.row_count = d->row_ws; ep.row_idx = d->row_ws + 4; ep.row_ids = d->row_ws + 4 + M;
+    }
   }
   if ((rc = nr_launch_gemm_nt(d->dtype, A, d->w_qkv, d->ldw, M, 3 * N, Kp, EPI_STORE, ep, s))) return rc;
   return nr_launch_attn(false, d->dtype, qkv, d->mask, y, nullptr, nullptr, d->n, d->L, d->heads, d->d_head,
@@ -295,7 +303,7 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
       ep.ids = d->ids; ep.ids_stride = 1; ep.Dtrue = d->d_model; ep.drop = nr_make_drop(d->p_in, d->seed_in);
       if (d->row_ws != nullptr && d->dtype == NR_BF16 && M >= 4096) {
         // only rows with a non-padding token id reach the table gradient: compact them, GEMM over those alone
-        if ((rc = nr_launch_compact_rows(d->ids, 1, M, d->row_ws, s))) return rc;
+        if (!d->row_ws_ready && (rc = nr_launch_compact_rows(d->ids, 1, M, d->row_ws, s))) return rc;
         ep.row_count = d->row_ws; ep.row_idx = d->row_ws + 4; ep.row_ids = d->row_ws + 4 + M;
       }
       rc = nr_launch_gemm_nt(d->dtype, G, w_qkv_t, ldwt, M, d->d_model, 3 * N, EPI_SCATTER, ep, s);

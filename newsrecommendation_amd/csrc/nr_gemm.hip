@@ -971,7 +971,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
   const int N = min(WBN, Ntot - nbase);
   constexpr int HN = (NT16 + 1) / 2;             // column tiles per wave
   const int tid = threadIdx.x, lane = tid & 63;
-  const bool compact = (EPI == EPI_SCATTER) && ep.row_count != nullptr;
+  const bool compact = (EPI == EPI_SCATTER || EPI == EPI_STORE) && ep.row_count != nullptr;
   if (compact) {
     M = *ep.row_count;                             // rows that survive the compaction (device side, no host sync)
     if (m0 >= M) return;
@@ -1042,6 +1042,9 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
   const bool b_lds = (EPI == EPI_STORE || EPI == EPI_STORE_TANH) && PK && ep.bias != nullptr && (nbase % 4 == 0) && N >= 4 &&
                      (((uintptr_t)ep.bias & 15) == 0);
   if (b_lds && wid == NW - 1) dma16(ep.bias + nbase + min(4 * lane, ((N - 4) / 4) * 4), lds0 + NS * STAGE);
+  // compacted STORE: the original row numbers of this tile (output rows are scattered back)
+  const bool r_lds = (EPI == EPI_STORE) && PK && compact && M >= 4 && (((uintptr_t)ep.row_idx & 15) == 0) && m0 + 255 < M;
+  if (r_lds && wid == NW - 2) dma16(ep.row_idx + m0 + 4 * lane, lds0 + NS * STAGE + 1024);
   // SCATTER: the 256 token ids of this tile
   const int32_t* tile_ids = compact ? ep.row_ids : ep.ids;
   const bool i_lds = (EPI == EPI_SCATTER) && !PK && (compact || ep.ids_stride == 1) && M >= 4 && (((uintptr_t)tile_ids & 15) == 0) &&
@@ -1214,7 +1217,8 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
         const int row = u / (WBN / 8), c0 = (u % (WBN / 8)) * 8;
         const int m = m0 + pass * 128 + row;
         if (m < M && c0 < N) {
-          bf16_t* dst = (bf16_t*)ep.C + (size_t)m * ep.ldc + nbase + c0;
+          const int mout = !compact ? m : (r_lds ? reinterpret_cast<const int*>(smem + NS * STAGE + 1024)[pass * 128 + row] : ep.row_idx[m]);
+          bf16_t* dst = (bf16_t*)ep.C + (size_t)mout * ep.ldc + nbase + c0;
           if (c0 + 8 <= N && (ep.ldc % 8) == 0 && (nbase % 8) == 0) {
             *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(sCb + row * SCB + c0);
           } else {
@@ -1287,7 +1291,7 @@ int launch_nt_dma_w(const RowSrc& A, const void* B, int ldb, int M, int N, int K
   constexpr size_t ring = (size_t)NS * STAGE, epi = (size_t)32 * (NT16 * 16 + 4) * sizeof(float);
   constexpr size_t epk = PK ? (size_t)128 * (NT16 * 16 + 8) * sizeof(bf16_t) : 0;
   constexpr size_t gtile = EPI == EPI_POOLBWD && PK ? (size_t)((12 * NT16 * 16 * 4 + 1023) / 1024) * 1024 + 1024
-                                                    : (EPI == EPI_SCATTER ? 2048 : 1024);
+                                                    : ((EPI == EPI_SCATTER || EPI == EPI_STORE) ? 2048 : 1024);
   constexpr size_t smem0 = ring > epi ? ring : epi, smem1 = smem0 > epk ? smem0 : epk, smem = smem1 + gtile;
   auto kern = gemm_nt_dma_kernel<EPI, NT16, PK, WM>;
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -1620,23 +1624,83 @@ int launch_tn_d(const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, fl
 // batch they are ~70 % of all rows (zero-padded title tails, empty history slots).  One pass, no host round trip:
 // 256 rows per workgroup, order kept inside a workgroup, workgroups append through one atomic counter.
 namespace {
-__global__ __launch_bounds__(256) void compact_rows_kernel(const int32_t* __restrict__ ids, int stride, int M, int32_t* __restrict__ ws) {
-  __shared__ int wave_cnt[4];
-  __shared__ int base;
+// ws: [0] live count, [1] dead count, [4 .. 4+M) live rows, [4+M .. 4+2M) their ids, [4+2M .. 4+3M) dead rows (if DEAD).
+// all_live (device flag, may be null): when set every row counts as live (table row 0 is not zero, so a padding token
+// does not gather a zero row and the forward may not treat it as one).
+template <bool DEAD>
+__global__ __launch_bounds__(256) void compact_rows_kernel(const int32_t* __restrict__ ids, int stride, int M, int32_t* __restrict__ ws,
+                                                           const int32_t* __restrict__ all_live) {
+  constexpr int RPT = 4;                                  // 1024 rows per workgroup: 4 batches of 256, order preserved
+  __shared__ int wave_cnt[RPT][4];
+  __shared__ int base, dbase;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int m = blockIdx.x * 256 + tid;
-  const int id = m < M ? ids[(size_t)m * stride] : 0;
-  const uint64_t bal = __ballot(id != 0);
-  if (lane == 0) wave_cnt[wid] = __popcll(bal);
-  __syncthreads();
-  if (tid == 0) base = atomicAdd(ws, wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
-  __syncthreads();
-  if (id != 0) {
-    int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wid; ++w) pos += wave_cnt[w];
-    ws[4 + pos] = m;
-    ws[4 + M + pos] = id;
+  const int row0 = blockIdx.x * 256 * RPT;
+  const bool keep_all = all_live != nullptr && *all_live != 0;
+  int id[RPT];
+  uint64_t bal[RPT];
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int m = row0 + j * 256 + tid;
+    id[j] = m < M ? ids[(size_t)m * stride] : 0;
+    bal[j] = __ballot(m < M && (id[j] != 0 || keep_all));
+    if (lane == 0) wave_cnt[j][wid] = __popcll(bal[j]);
   }
+  __syncthreads();
+  if (tid == 0) {
+    int nl = 0;
+    for (int j = 0; j < RPT; ++j) nl += wave_cnt[j][0] + wave_cnt[j][1] + wave_cnt[j][2] + wave_cnt[j][3];
+    base = atomicAdd(ws, nl);
+    if (DEAD) dbase = atomicAdd(ws + 1, min(256 * RPT, M - row0) - nl);
+  }
+  __syncthreads();
+  int before = 0;                                         // live rows of this workgroup in front of (j, tid)
+#pragma unroll
+  for (int j = 0; j < RPT; ++j) {
+    const int m = row0 + j * 256 + tid;
+    int pos = before + __popcll(bal[j] & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wid; ++w) pos += wave_cnt[j][w];
+    const bool live = (bal[j] >> lane) & 1ull;
+    if (live) {
+      ws[4 + base + pos] = m;
+      ws[4 + M + base + pos] = id[j];
+    } else if (DEAD && m < M) {
+      ws[4 + 2 * M + dbase + (j * 256 + tid - pos)] = m;
+    }
+    before += wave_cnt[j][0] + wave_cnt[j][1] + wave_cnt[j][2] + wave_cnt[j][3];
+  }
+}
+
+// qkv rows of padding tokens: x = 0 there, so the projection is the bias itself.  A thread owns one 16-byte column chunk
+// (its bias values are converted once); a workgroup walks batches of 64 row numbers staged through LDS.
+__global__ __launch_bounds__(256) void bias_rows_kernel(bf16_t* __restrict__ C, int ldc, int N, const float* __restrict__ bias,
+                                                        const int32_t* __restrict__ rows, const int32_t* __restrict__ count) {
+  __shared__ int srow[64];
+  const int cpr = N / 8, n = *count, tid = threadIdx.x;
+  for (int c0 = 0; c0 < cpr; c0 += 256) {
+    const int c = c0 + tid;
+    Chunk o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.h[e] = (bf16_t)((bias && c < cpr) ? bias[c * 8 + e] : 0.f);
+    for (int r0 = blockIdx.x * 64; r0 < n; r0 += gridDim.x * 64) {
+      __syncthreads();
+      if (tid < 64) srow[tid] = r0 + tid < n ? rows[r0 + tid] : -1;
+      __syncthreads();
+      if (c < cpr) {
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) {
+          const int r = srow[i];
+          if (r >= 0) *reinterpret_cast<uint4*>(C + (size_t)r * ldc + c * 8) = o.u;
+        }
+      }
+    }
+  }
+}
+
+__global__ void row0_flag_kernel(const bf16_t* __restrict__ row0, int cols, int32_t* __restrict__ flag) {
+  bool nz = false;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) nz |= (float)row0[c] != 0.f;
+  const int any = __syncthreads_or(nz);
+  if (threadIdx.x == 0) *flag = any;
 }
 }  // namespace
 
@@ -1644,7 +1708,29 @@ int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* w
   NR_CHECK_ARG(ids != nullptr && ws != nullptr && M > 0 && ids_stride >= 1, "compact_rows: bad arguments");
   NR_CHECK_HIP(hipMemsetAsync(ws, 0, 4 * sizeof(int32_t), stream));
   NrProfScope ps(stream, "compact_rows[M=%d]", M);
-  hipLaunchKernelGGL(compact_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, ids, ids_stride, M, ws);
+  hipLaunchKernelGGL(compact_rows_kernel<false>, dim3((M + 1023) / 1024), dim3(256), 0, stream, ids, ids_stride, M, ws, (const int32_t*)nullptr);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+// Forward flavour: ws int32 [3*M + 4]; ws[2] = 1 when row 0 of the (bf16) table is not all zero -> every row live.
+int nr_launch_compact_rows_fwd(const int32_t* ids, int M, const void* table_row0, int cols, int32_t* ws, hipStream_t stream) {
+  NR_CHECK_ARG(ids != nullptr && ws != nullptr && M > 0 && table_row0 != nullptr, "compact_rows_fwd: bad arguments");
+  NR_CHECK_HIP(hipMemsetAsync(ws, 0, 4 * sizeof(int32_t), stream));
+  NrProfScope ps(stream, "compact_rows[M=%d]", M);
+  hipLaunchKernelGGL(row0_flag_kernel, dim3(1), dim3(256), 0, stream, (const bf16_t*)table_row0, cols, ws + 2);
+  hipLaunchKernelGGL(compact_rows_kernel<true>, dim3((M + 1023) / 1024), dim3(256), 0, stream, ids, 1, M, ws, (const int32_t*)(ws + 2));
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_t* rows, const int32_t* count, int max_rows,
+                        hipStream_t stream) {
+  NR_CHECK_ARG(N % 8 == 0 && ldc % 8 == 0, "bias_rows: N=%d / ldc=%d must be multiples of 8", N, ldc);
+  NrProfScope ps(stream, "bias_rows[max=%d,N=%d]", max_rows, N);
+  size_t grid = ((size_t)max_rows + 63) / 64;
+  if (grid > 256 * 8) grid = 256 * 8;
+  hipLaunchKernelGGL(bias_rows_kernel, dim3((unsigned)grid), dim3(256), 0, stream, (bf16_t*)C, ldc, N, bias, rows, count);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -1689,7 +1775,9 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
   static const int dma_min_k = getenv("NR_DMA_MIN_K") ? atoi(getenv("NR_DMA_MIN_K")) : 192;
   if (dense_bf16 && !no_dma && K >= dma_min_k && ldb >= kr32 && A.ld >= K) {
     // B must be zero beyond K up to the next multiple of 32 (nr_cast_pad with such an ld guarantees it)
-    NrProfScope ps(stream, "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d]", epi, M, N, K);
+    // with row compaction only the live rows (count on the device) are multiplied: M is then an upper bound
+    NrProfScope ps(stream, ep.row_count ? "gemm_nt_dma_live[bf16,epi=%d,Mmax=%d,N=%d,K=%d]" : "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d]", epi,
+                   M, N, K);
     const int c13 = ((N + 207) / 208) * 13, c20 = ((N + 319) / 320) * 20;   // fewer padded column tiles wins
     if (c13 < c20) return launch_nt_dma_e<13>(A, B, ldb, M, N, K, epi, ep, stream);
     return launch_nt_dma_e<20>(A, B, ldb, M, N, K, epi, ep, stream);

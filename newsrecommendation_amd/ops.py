@@ -128,16 +128,19 @@ class MHSAFunction(Function):
         keep_rows = gather and any(ctx.needs_input_grad[1:7])
         Kp = round_up(d_model, ch)
         x_rows = torch.empty(n * L, Kp, dtype=torch_dtype(code), device=dev) if keep_rows else None
+        # scratch for the device-side compaction of non-padding rows (forward: live rows, their ids, padding rows)
+        row_ws = torch.empty(3 * n * L + 4, dtype=torch.int32, device=dev) if keep_rows and code == _lib.NR_BF16 else None
         d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=d_head, dtype=code,
                           src_kind=NR_SRC_GATHER if gather else NR_SRC_DENSE, x=ptr(src), ldx=ldx, ids=ptr(ids),
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
-                          x_rows=ptr(x_rows), ld_rows=Kp)
+                          x_rows=ptr(x_rows), ld_rows=Kp, row_ws=ptr(row_ws))
         # the fused title-level kernel keeps Q|K|V on chip: without a backward they are never written to HBM
         fused = bool(_lib.lib().nr_mhsa_fwd_fused(C.byref(d)))
         qkv = None if (fused and not need_bwd) else torch.empty(n * L, 3 * N, dtype=torch_dtype(code), device=dev)
         check(_lib.lib().nr_mhsa_fwd(C.byref(d), ptr(qkv), ptr(y), _stream()), "nr_mhsa_fwd")
         ctx.cfg, ctx.dims = cfg, (n, L, N, d_model, heads, d_head, ldx, gather)
+        ctx.row_ws = row_ws if ctx.needs_input_grad[0] else None     # the table-gradient GEMM reuses the compaction
         ctx.save_for_backward(src, ids, mask_c, w_p, b_p, wcat, qkv, x_rows)
         return y
 
@@ -155,18 +158,22 @@ class MHSAFunction(Function):
         db = torch.zeros(3 * N, dtype=torch.float32, device=dev)
         need_x = ctx.needs_input_grad[0]
         dx = dtable = w_t = row_ws = None
+        ws_ready = False
         if need_x:
             w_t = pack(wcat, code, transpose=True)                     # [d_model, 3N]
             if gather:
                 dtable = torch.zeros(cfg["table_shape"], dtype=torch.float32, device=dev)
-                row_ws = torch.empty(2 * n * L + 4, dtype=torch.int32, device=dev)     # live-row compaction scratch
+                row_ws, ws_ready = ctx.row_ws, ctx.row_ws is not None
+                if row_ws is None:
+                    row_ws = torch.empty(3 * n * L + 4, dtype=torch.int32, device=dev)     # live-row compaction scratch
             else:
                 dx = torch.empty(n, L, ldx, dtype=torch_dtype(code), device=dev)
         d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=d_head, dtype=code,
                           src_kind=NR_SRC_GATHER if gather else NR_SRC_DENSE, x=ptr(src), ldx=ldx, ids=ptr(ids),
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
-                          x_rows=ptr(x_rows), ld_rows=x_rows.shape[1] if x_rows is not None else 0, row_ws=ptr(row_ws))
+                          x_rows=ptr(x_rows), ld_rows=x_rows.shape[1] if x_rows is not None else 0, row_ws=ptr(row_ws),
+                          row_ws_ready=int(ws_ready))
         check(_lib.lib().nr_mhsa_bwd(C.byref(d), ptr(qkv), ptr(dy), ptr(dqkv), ptr(w_t), w_t.shape[1] if w_t is not None else 0,
                                      ptr(dw), ptr(db), ptr(dx), ptr(dtable), _stream()), "nr_mhsa_bwd")
         gx = dtable if gather else dx

@@ -113,3 +113,37 @@ def test_compact_history_option_changes_nothing_observable(tag):
     assert g0.keys() == g1.keys()
     for k in g0:
         assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * float(g0[k].abs().max()) + 1e-8, k
+
+
+@pytest.mark.parametrize("nonzero_row0", [False, True])
+def test_bf16_padding_row_compaction_respects_table_row_zero(nonzero_row0):
+    """bf16 NRMS at MIND shapes runs the QKV projection and the table-gradient GEMM over the rows whose token id is not
+    the padding id (device-side compaction) and writes the bias into the projections of the others.  That shortcut
+    assumes table row 0 is zero; nn.Embedding(padding_idx=0) does not enforce it (src/model/NRMS.py:70-73), so a
+    table with a NON-zero row 0 must switch the shortcut off by itself.  Checked against the oracle either way."""
+    from helpers import load_case
+    tag = "nrms_mind_pad"
+    z, cfg, sd = load_case(tag)
+    sd = {k: v.clone() for k, v in sd.items()}
+    if nonzero_row0:
+        g = torch.Generator().manual_seed(9)
+        sd[table_key(tag)][0] = torch.randn(sd[table_key(tag)].shape[1], generator=g) * 0.4
+    from newsrecommendation_amd.model import NRMS
+    from types import SimpleNamespace
+    args = SimpleNamespace(**vars(cfg), compute_dtype="bf16")
+    m = NRMS.Model(args, sd[table_key(tag)].numpy())
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    hist, mask, cand, label = batch_of(z)
+    assert float((hist == 0).float().mean()) > 0.05             # the batch has padding tokens
+    loss, score = m(hist, mask, cand, label)
+    loss.backward()
+    lo, so, go = oracle_run(tag, z, cfg, sd)
+    assert_close(loss, lo, 3e-2, name="loss")
+    assert_close(score, so, 3e-2, name="score")
+    for name, p in m.named_parameters():
+        if p.requires_grad and name in go:
+            # absolute floor: d W_K.bias is analytically ~0 (a constant key shift leaves the softmax unchanged), only
+            # bf16 rounding noise of the dK entries remains there
+            assert_close(p.grad, go[name], 3e-4, 1e-1, name="d" + name)
+    assert float(dict(m.named_parameters())[table_key(tag)].grad[0].abs().max()) == 0.0
