@@ -569,7 +569,7 @@ int nr_pad_blend_fwd(const float* x, const float* mask, const float* pad, void* 
 int nr_pad_blend_bwd(const void* dout, const float* mask, float* dx, float* dpad, int n, int L, int N, int dtype,
                      nr_stream_t stream) {
   NR_CHECK_ARG(dout && dx && n > 0 && L > 0 && N > 0, "pad_blend_bwd: null/empty");
-  const int rows = n * L, rpb = 64;
+  const int rows = n * L, rpb = 16;   // 16 rows per workgroup: enough workgroups to fill the chip at the user level (25 600 rows)
   hipStream_t s = (hipStream_t)stream;
   NrProfScope ps(s, "pad_blend_bwd[n=%d,L=%d,N=%d]", n, L, N);
   if (dtype == NR_BF16)
