@@ -7,7 +7,9 @@
 
 // launchers defined in nr_attn.hip / nr_pool.hip
 int nr_launch_attn(bool bwd, int dtype, const void* qkv, const float* mask, void* y, const void* dy, void* dqkv, int n, int L,
-                   int heads, int d_head, const DropCfg& drop, hipStream_t stream);
+                   int heads, int d_head, const DropCfg& drop, hipStream_t stream, const uint32_t* tmask = nullptr,
+                   const float* bias = nullptr);
+bool nr_attn_pad_ok(int dtype, int L, int d_head, const void* p0, const void* p1);
 int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
                             float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s);
 int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float* w2, const float* alpha, const float* g,
@@ -249,6 +251,7 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   }
   NR_CHECK_ARG(qkv != nullptr, "mhsa_fwd: the unfused path needs the qkv buffer (see nr_mhsa_fwd_fused)");
   EpiArgs ep = store_epi(qkv, 3 * N, d->dtype, d->b_qkv, 0);
+  const uint32_t* tmask = nullptr;
   if (d->x_rows != nullptr && d->src_kind == NR_SRC_GATHER) {
     // gather + dropout once into x_rows (kept for the backward), then a plain dense projection GEMM
     NR_CHECK_ARG(d->ld_rows >= Kp && d->ld_rows % nr_chunk(d->dtype) == 0, "mhsa_fwd: ld_rows=%d must cover %d", d->ld_rows, Kp);
@@ -258,14 +261,20 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
       // Padding tokens (id 0) gather the zero row of the table: their projection is the bias.  Project the live rows
       // only (compacted on the device) and write the bias into the others.  If table row 0 is not zero, the
       // compaction keeps every row and nothing changes.
-      if ((rc = nr_launch_compact_rows_fwd(d->ids, M, d->x, d->d_model, d->row_ws, s))) return rc;
-      if ((rc = nr_launch_bias_rows(qkv, 3 * N, 3 * N, d->b_qkv, d->row_ws + 4 + 2 * (size_t)M, d->row_ws + 1, M, s))) return rc;
+      if ((rc = nr_launch_compact_rows_fwd(d->ids, M, d->n, d->L, d->x, d->d_model, d->row_ws, s))) return rc;
       ep.row_count = d->row_ws; ep.row_idx = d->row_ws + 4; ep.row_ids = d->row_ws + 4 + M;
+      // Sequences made of padding tokens only (empty history slots, ~45 % of the titles of a MIND-shaped batch): the
+      // attention kernels take their Q|K|V from the bias themselves (per-sequence live mask == 0), so those qkv rows are
+      // neither written here nor read there.  The bias goes into the padding rows of the other sequences.
+      if (d->b_qkv != nullptr && nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, y))
+        tmask = reinterpret_cast<const uint32_t*>(d->row_ws + 4 + 3 * (size_t)M);
+      if ((rc = nr_launch_bias_rows(qkv, 3 * N, 3 * N, d->b_qkv, d->row_ws + 4 + 2 * (size_t)M, d->row_ws + 1, M, tmask, d->L, s)))
+        return rc;
     }
   }
   if ((rc = nr_launch_gemm_nt(d->dtype, A, d->w_qkv, d->ldw, M, 3 * N, Kp, EPI_STORE, ep, s))) return rc;
   return nr_launch_attn(false, d->dtype, qkv, d->mask, y, nullptr, nullptr, d->n, d->L, d->heads, d->d_head,
-                        nr_make_drop(d->p_out, d->seed_out), s);
+                        nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr);
 }
 
 int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dqkv, const void* w_qkv_t, int ldwt,
@@ -278,8 +287,18 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
   const int N = d->heads * d->d_head, M = d->n * d->L, ch = nr_chunk(d->dtype), Kp = round_up(d->d_model, ch);
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
+  // row_ws_ready: the forward compacted the rows and (when the attention kernels support it) left the qkv rows of
+  // padding tokens unwritten -- the backward attention must substitute the bias exactly as the forward one did
+  const uint32_t* tmask = nullptr;
+  if (d->row_ws != nullptr && d->row_ws_ready && d->src_kind == NR_SRC_GATHER && d->dtype == NR_BF16 && M >= 4096 &&
+      (3 * N) % 8 == 0 && d->b_qkv != nullptr && d->x_rows != nullptr && nr_attn_pad_ok(d->dtype, d->L, d->d_head, nullptr, nullptr)) {
+    // shape-wise the forward substituted; whether it really did also hung on the alignment of its qkv / y
+    NR_CHECK_ARG(nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, dqkv) && (((uintptr_t)dy) & 7) == 0,
+                 "mhsa_bwd: the forward left padding rows of qkv unwritten; qkv / dy / dqkv must be 8-byte aligned");
+    tmask = reinterpret_cast<const uint32_t*>(d->row_ws + 4 + 3 * (size_t)M);
+  }
   if ((rc = nr_launch_attn(true, d->dtype, qkv, d->mask, nullptr, dy, dqkv, d->n, d->L, d->heads, d->d_head,
-                           nr_make_drop(d->p_out, d->seed_out), s)))
+                           nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr)))
     return rc;
   // dW_qkv[3N, d_model] += dQKV^T . X ; db += colsum(dQKV).  X: the rows saved by the forward when present.
   RowSrc Xs = A;

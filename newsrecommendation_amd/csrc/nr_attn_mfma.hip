@@ -15,6 +15,7 @@
 // Softmax is the reference's (src/model/model_utils.py:47-53): exp, key mask after exp, denominator
 // sum + 1e-8, evaluated in the stable form with the row max factored out.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "nr_common.h"
 
@@ -36,6 +37,8 @@ struct AttnMArgs {
   int vec;            // 1: d % 4 == 0 and all head slices are 4-element aligned -> vector staging / stores
   float scale;
   DropCfg drop;
+  const uint32_t* tmask;  // optional [n]: live-token bit mask of each sequence.  0 = padding tokens only: every Q|K|V row
+  const float* bias;      //   of that sequence is this bias [3N]; its qkv rows are never written and never read
 };
 
 __device__ __forceinline__ int rowof(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -573,11 +576,16 @@ constexpr float LOG2E = 1.4426950408889634f;
 // The piece -> (row, head, column) map is the same for every item, so it is computed once per thread.
 // Pad rows/columns of the images are zeroed once: nothing ever overwrites them (outputs leave from registers).
 // PT = pieces per thread and matrix: needs L * AW * d / 4 <= PT * AW * 64  (PT = 3 up to L * d = 768, else 4)
+// two packed words per piece (the backward kernel sits at its register limit): token row | head slot << 8, and
+// offset in the image block | first column inside the panel row << 16
 template <int PT> struct Pieces {
-  int goff3[PT], goff1[PT], loff[PT], hh[PT];   // offsets in a [*, 3N] / [*, N] row-major tensor, in the image block
-  int poff[PT];                                 // offset in a row-major [L][AW*d + 8] output panel
+  int rh[PT], lq[PT];
+  __device__ __forceinline__ int row(int t) const { return rh[t] & 0xff; }
+  __device__ __forceinline__ int hh(int t) const { return rh[t] >> 8; }
+  __device__ __forceinline__ int loff(int t) const { return lq[t] & 0xffff; }
+  __device__ __forceinline__ int q4(int t) const { return lq[t] >> 16; }
 };
-template <int PT> __device__ __forceinline__ Pieces<PT> make_pieces(int tid, int L, int d, int N, int nimg) {
+template <int PT> __device__ __forceinline__ Pieces<PT> make_pieces(int tid, int L, int d, int nimg) {
   Pieces<PT> pc;
   const int pph = d >> 2, ppr = AW * pph;            // pieces per head row / per panel row
   const uint32_t inv_ppr = (65536 + ppr - 1) / ppr, inv_pph = (65536 + pph - 1) / pph;   // exact for p < 1024, divisors <= 40
@@ -587,36 +595,46 @@ template <int PT> __device__ __forceinline__ Pieces<PT> make_pieces(int tid, int
     const int row = (int)(((uint32_t)p * inv_ppr) >> 16), q = p - row * ppr;
     const int h = (int)(((uint32_t)q * inv_pph) >> 16), c = 4 * (q - h * pph);
     const bool ok = row < L;
-    pc.hh[t] = ok ? h : AW;                           // AW = never active
-    pc.goff3[t] = row * 3 * N + 4 * q;
-    pc.goff1[t] = row * N + 4 * q;
-    pc.loff[t] = h * nimg * IMG + ioff(row & 31, c);
-    pc.poff[t] = (row & 31) * (AW * d + 8) + 4 * q;
+    pc.rh[t] = (row & 31) | ((ok ? h : AW) << 8);     // head slot AW = never active
+    pc.lq[t] = (h * nimg * IMG + ioff(row & 31, c)) | ((4 * q) << 16);
   }
   return pc;
 }
 template <int PT> struct Panel { bf16x4 v[PT]; };
+// src: first element of the panel (row 0, first column of the head group) in a row-major tensor with row stride ld.
 template <int PT>
-__device__ __forceinline__ void panel_load(Panel<PT>& r, const bf16_t* __restrict__ src, const int (&goff)[PT], const int (&hh)[PT],
-                                           int hcount) {
+__device__ __forceinline__ void panel_load(Panel<PT>& r, const bf16_t* __restrict__ src, int ld, const Pieces<PT>& pc, int hcount) {
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
     r.v[t] = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-    if (hh[t] < hcount) r.v[t] = *reinterpret_cast<const bf16x4*>(src + (uint32_t)goff[t]);
+    if (pc.hh(t) < hcount) r.v[t] = *reinterpret_cast<const bf16x4*>(src + (uint32_t)(pc.row(t) * ld + pc.q4(t)));
   }
 }
 template <bool DROP, int PT>
-__device__ __forceinline__ void panel_put(const Panel<PT>& r, bf16_t* img0, const Pieces<PT>& pc, const DropCfg& drop, uint32_t eidx0) {
+__device__ __forceinline__ void panel_put(const Panel<PT>& r, bf16_t* img0, const Pieces<PT>& pc, const DropCfg& drop, uint32_t eidx0,
+                                          int erow) {
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
-    if (pc.hh[t] < AW) {
+    if (pc.hh(t) < AW) {
       bf16x4 v = r.v[t];
       if (DROP && drop.thresh) {
-        const uint32_t kb = nr_keep4(drop.key, eidx0 + (uint32_t)pc.goff1[t], drop.thresh);
+        const uint32_t kb = nr_keep4(drop.key, eidx0 + (uint32_t)(pc.row(t) * erow + pc.q4(t)), drop.thresh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ((kb >> e) & 1u) ? (bf16_t)((float)v[e] * drop.scale) : (bf16_t)0.f;
       }
-      *reinterpret_cast<bf16x4*>(img0 + pc.loff[t]) = v;
+      *reinterpret_cast<bf16x4*>(img0 + pc.loff(t)) = v;
+    }
+  }
+}
+// Q / K / V images of a sequence made of padding tokens only: every row is the bias (table in LDS), nothing was loaded
+template <int PT>
+__device__ __forceinline__ void panel_put_bias(bf16_t* img0, const Pieces<PT>& pc, const bf16_t* sbias, int hcount) {
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    if (pc.hh(t) < AW) {
+      bf16x4 v = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+      if (pc.hh(t) < hcount) v = *reinterpret_cast<const bf16x4*>(sbias + pc.q4(t));
+      *reinterpret_cast<bf16x4*>(img0 + pc.loff(t)) = v;
     }
   }
 }
@@ -648,19 +666,21 @@ __device__ __forceinline__ void acc_t_to_panel(const f32x16& acc, bf16_t* panel,
   }
 }
 template <int PT>
-__device__ __forceinline__ void panel_store(const bf16_t* panel, bf16_t* __restrict__ dst, const int (&goff)[PT],
-                                            const Pieces<PT>& pc, int hcount) {
+__device__ __forceinline__ void panel_store(const bf16_t* panel, int ops, bf16_t* __restrict__ dst, int ld, const Pieces<PT>& pc,
+                                            int hcount) {
 #pragma unroll
   for (int t = 0; t < PT; ++t)
-    if (pc.hh[t] < hcount) *reinterpret_cast<bf16x4*>(dst + (uint32_t)goff[t]) = *reinterpret_cast<const bf16x4*>(panel + pc.poff[t]);
+    if (pc.hh(t) < hcount)
+      *reinterpret_cast<bf16x4*>(dst + (uint32_t)(pc.row(t) * ld + pc.q4(t))) =
+          *reinterpret_cast<const bf16x4*>(panel + pc.row(t) * ops + pc.q4(t));
 }
 
 // softmax scale and log2(e) are folded into one fma feeding v_exp_f32; the mask multiply only exists when a mask is
 // given; one dropout hash serves two elements; all lane offsets are 32-bit.
-template <bool HAS_MASK, int PT>
+template <bool HAS_MASK, int PT, bool SUB>
 __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR address math
   bf16_t* img0 = reinterpret_cast<bf16_t*>(smem);
   bf16_t* base = img0 + (size_t)wid * 3 * IMG;
   bf16_t *sQ = base, *sK = base + IMG, *sV = base + 2 * IMG;
@@ -671,33 +691,48 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   const int N = a.N, L = a.L, d = a.d, N3 = 3 * a.N, ops = AW * a.d + 8;
   const int h2 = lane >> 5;
   const float c1 = a.scale * LOG2E;   // scale > 0: the row maximum can be taken on the raw scores
-  const Pieces<PT> pc = make_pieces<PT>(tid, L, d, N, 3);
+  const Pieces<PT> pc = make_pieces<PT>(tid, L, d, 3);
   zero_images(img0, AW * 3, tid);
+  bf16_t* sBias = sOut + 32 * ops;                     // SUB: bias [3N] as bf16 (what the projection of a zero row is)
+  if (SUB)
+    for (int i = tid; i < N3; i += AW * 64) sBias[i] = (bf16_t)a.bias[i];
 
   // One workgroup walks ALL heads of a sequence (AW heads at a time) before moving on; the panels of the NEXT item
   // are loaded into registers while the current item is computed.
   const int hgroups = (a.heads + AW - 1) / AW, stride = gridDim.x;
   ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};   // blockIdx.x < n by launch
   Panel<PT> rq, rk, rv;
+  bool dead_next = false;                                // the item sitting in rq / rk / rv is all padding
   auto prefetch = [&](const ItemIter& t) {
-    const bf16_t* src = qkv + (size_t)t.sb * L * N3 + t.hg * AW * d;
+    const int hoff = t.hg * AW * d;
+    const bf16_t* src = qkv + (size_t)t.sb * L * N3 + hoff;
     const int hcount = min(AW, a.heads - t.hg * AW);
-    panel_load(rq, src, pc.goff3, pc.hh, hcount);
-    panel_load(rk, src + N, pc.goff3, pc.hh, hcount);
-    panel_load(rv, src + 2 * N, pc.goff3, pc.hh, hcount);
+    dead_next = SUB && a.tmask[t.sb] == 0;               // a sequence of padding tokens only: Q|K|V = bias, nothing to load
+    if (!dead_next) {
+      panel_load(rq, src, N3, pc, hcount);
+      panel_load(rk, src + N, N3, pc, hcount);
+      panel_load(rv, src + 2 * N, N3, pc, hcount);
+    }
   };
-  prefetch(nx);
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
-  __syncthreads();
+  __syncthreads();                                       // images zeroed, bias table in LDS
+  prefetch(nx);
   for (; it.sb < a.n; it.next(hgroups, stride)) {
     const int head = it.hg * AW + wid;
     const bool active = head < a.heads;
     const size_t row0 = (size_t)it.sb * L;
     const int Ls = active ? L : 0;                       // inactive waves store nothing
-    panel_put<false>(rq, img0, pc, nodrop, 0);
-    panel_put<false>(rk, img0 + IMG, pc, nodrop, 0);
-    panel_put<false>(rv, img0 + 2 * IMG, pc, nodrop, 0);
+    if (SUB && dead_next) {
+      const int hoff = it.hg * AW * d, hcount = min(AW, a.heads - it.hg * AW);
+      panel_put_bias(img0, pc, sBias + hoff, hcount);
+      panel_put_bias(img0 + IMG, pc, sBias + N + hoff, hcount);
+      panel_put_bias(img0 + 2 * IMG, pc, sBias + 2 * N + hoff, hcount);
+    } else {
+      panel_put<false>(rq, img0, pc, nodrop, 0, 0);
+      panel_put<false>(rk, img0 + IMG, pc, nodrop, 0, 0);
+      panel_put<false>(rv, img0 + 2 * IMG, pc, nodrop, 0, 0);
+    }
     if (HAS_MASK && lane < 32) sMask[lane] = (lane < Ls) ? a.mask[row0 + lane] : 0.f;
     __syncthreads();
     nx.next(hgroups, stride);
@@ -732,14 +767,14 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
     const uint32_t e0 = (uint32_t)(row0 * N) + (uint32_t)((active ? head : 0) * d);
     acc_t_to_panel<true>(ctx, sOut, ops, wid, Ls, d, lane, a.drop, e0, (uint32_t)N);
     __syncthreads();   // output panel complete; every wave is done with its images
-    panel_store<PT>(sOut, y + row0 * N + it.hg * AW * d, pc.goff1, pc, min(AW, a.heads - it.hg * AW));
+    panel_store<PT>(sOut, ops, y + row0 * N + it.hg * AW * d, N, pc, min(AW, a.heads - it.hg * AW));
   }
 }
 
-template <bool HAS_MASK, int PT>
+template <bool HAS_MASK, int PT, bool SUB>
 __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void bwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR address math
   bf16_t* img0 = reinterpret_cast<bf16_t*>(smem);
   bf16_t* base = img0 + (size_t)wid * 4 * IMG;
   bf16_t *sQ = base, *sK = base + IMG, *sV = base + 2 * IMG, *sG = base + 3 * IMG;
@@ -751,35 +786,49 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
   bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.dqkv);
   const int h2 = lane >> 5, li = lane & 31;
   const float c1 = a.scale * LOG2E;
-  const Pieces<PT> pc = make_pieces<PT>(tid, L, d, N, 4);
+  const Pieces<PT> pc = make_pieces<PT>(tid, L, d, 4);
   zero_images(img0, AW * 4, tid);
+  bf16_t* sBias = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(img0 + (size_t)AW * 4 * IMG) + AW * 128);   // SUB: bias [3N] as bf16
+  if (SUB)
+    for (int i = tid; i < N3; i += AW * 64) sBias[i] = (bf16_t)a.bias[i];
 
   const int hgroups = (a.heads + AW - 1) / AW, stride = gridDim.x;
   ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};
   Panel<PT> rq, rk, rv, rg;
+  bool dead_next = false;
   auto prefetch = [&](const ItemIter& t) {
     const size_t r0 = (size_t)t.sb * L;
     const int hd = t.hg * AW * d;
     const bf16_t* src = qkv + r0 * N3 + hd;
     const int hcount = min(AW, a.heads - t.hg * AW);
-    panel_load(rq, src, pc.goff3, pc.hh, hcount);
-    panel_load(rk, src + N, pc.goff3, pc.hh, hcount);
-    panel_load(rv, src + 2 * N, pc.goff3, pc.hh, hcount);
-    panel_load(rg, dy + r0 * N + hd, pc.goff1, pc.hh, hcount);
+    dead_next = SUB && a.tmask[t.sb] == 0;
+    if (!dead_next) {
+      panel_load(rq, src, N3, pc, hcount);
+      panel_load(rk, src + N, N3, pc, hcount);
+      panel_load(rv, src + 2 * N, N3, pc, hcount);
+    }
+    panel_load(rg, dy + r0 * N + hd, N, pc, hcount);      // the upstream gradient has no padding rows
   };
-  prefetch(nx);
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
-  __syncthreads();
+  __syncthreads();                                       // images zeroed, bias table in LDS
+  prefetch(nx);
   for (; it.sb < a.n; it.next(hgroups, stride)) {
     const int head = it.hg * AW + wid;
     const bool active = head < a.heads;
     const size_t row0 = (size_t)it.sb * L;
     const int Ls = active ? L : 0;
-    panel_put<false>(rq, img0, pc, nodrop, 0);
-    panel_put<false>(rk, img0 + IMG, pc, nodrop, 0);
-    panel_put<false>(rv, img0 + 2 * IMG, pc, nodrop, 0);
-    panel_put<true>(rg, img0 + 3 * IMG, pc, a.drop, (uint32_t)(row0 * N) + (uint32_t)(it.hg * AW * d));
+    if (SUB && dead_next) {
+      const int hoff = it.hg * AW * d, hcount = min(AW, a.heads - it.hg * AW);
+      panel_put_bias(img0, pc, sBias + hoff, hcount);
+      panel_put_bias(img0 + IMG, pc, sBias + N + hoff, hcount);
+      panel_put_bias(img0 + 2 * IMG, pc, sBias + 2 * N + hoff, hcount);
+    } else {
+      panel_put<false>(rq, img0, pc, nodrop, 0, 0);
+      panel_put<false>(rk, img0 + IMG, pc, nodrop, 0, 0);
+      panel_put<false>(rv, img0 + 2 * IMG, pc, nodrop, 0, 0);
+    }
+    panel_put<true>(rg, img0 + 3 * IMG, pc, a.drop, (uint32_t)(row0 * N) + (uint32_t)(it.hg * AW * d), N);
     if (HAS_MASK && lane < 32) sMask[lane] = (lane < Ls) ? a.mask[row0 + lane] : 0.f;
     __syncthreads();
     nx.next(hgroups, stride);
@@ -1099,7 +1148,7 @@ __global__ __launch_bounds__(AW * 64) void fused_fwd_kernel(FusedArgs a) {
   constexpr int NWL = 64 * WCH / (AW * 64);       // weight chunks staged per thread per head
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* sW = reinterpret_cast<bf16_t*>(smem);                   // [2][64][WS]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR address math
   bf16_t* img = sW + 2 * 64 * WS + (size_t)wid * 4 * IMG;
   bf16_t *sQ = img, *sK = img + IMG, *sV = img + 2 * IMG, *sO = img + 3 * IMG;
   float* sMask = reinterpret_cast<float*>(sW + 2 * 64 * WS + (size_t)AW * 4 * IMG) + wid * 32;
@@ -1267,15 +1316,16 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   const size_t panel = (size_t)32 * (AW * a.d + 8) * sizeof(bf16_t);
   const size_t smem = bwd ? AW * (4 * IMG * sizeof(bf16_t) + 128 * sizeof(float))
                           : AW * (3 * IMG * sizeof(bf16_t) + 32 * sizeof(float)) + panel;
-  const bool p3 = a.L * a.d <= 768;
-  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(AW * 64), smem, stream, a); };
-  if (bwd) {
-    if (a.mask) p3 ? go(bwd_kernel<true, 3>) : go(bwd_kernel<true, 4>);
-    else p3 ? go(bwd_kernel<false, 3>) : go(bwd_kernel<false, 4>);
-  } else {
-    if (a.mask) p3 ? go(fwd_kernel<true, 3>) : go(fwd_kernel<true, 4>);
-    else p3 ? go(fwd_kernel<false, 3>) : go(fwd_kernel<false, 4>);
-  }
+  const bool p3 = a.L * a.d <= 768, sub = a.tmask != nullptr;
+  const size_t smem_s = smem + (sub ? (size_t)3 * a.N * sizeof(bf16_t) : 0);
+  auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(AW * 64), smem_s, stream, a); };
+  auto pick = [&](auto tag_mask, auto tag_sub) {
+    constexpr bool HM = decltype(tag_mask)::value, SB = decltype(tag_sub)::value;
+    if (bwd) p3 ? go(bwd_kernel<HM, 3, SB>) : go(bwd_kernel<HM, 4, SB>);
+    else p3 ? go(fwd_kernel<HM, 3, SB>) : go(fwd_kernel<HM, 4, SB>);
+  };
+  if (a.mask) sub ? pick(std::true_type{}, std::true_type{}) : pick(std::true_type{}, std::false_type{});
+  else sub ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -1307,10 +1357,21 @@ int launch_t(bool bwd, const AttnMArgs& a, hipStream_t stream) {
 // L <= 32: every dtype; 32 < L <= 64: the bf16 fast path only (vector-aligned slices); else the LDS/VALU kernels
 bool nr_attn_mfma_supported(int L, int d_head) { return L >= 1 && L <= 64 && d_head >= 1 && d_head <= 32; }
 
+// Padding-token substitution (tmask / bias) exists on the bf16 panel kernels only: L <= 32, d_head % 4 == 0, 8-byte
+// aligned tensors.  nr_attn_pad_ok tells the caller beforehand; a launch that asks for it elsewhere is an error.
+bool nr_attn_pad_ok(int dtype, int L, int d_head, const void* p0, const void* p1) {
+  static const bool old_path = getenv("NR_ATTN_OLD") != nullptr || getenv("NR_ATTN_VALU") != nullptr ||
+                               getenv("NR_NO_PAD_SUB") != nullptr;
+  return !old_path && dtype == NR_BF16 && L >= 1 && L <= 32 && d_head >= 4 && d_head <= 32 && d_head % 4 == 0 &&
+         (((uintptr_t)p0 | (uintptr_t)p1) & 7) == 0;
+}
+
 int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask, void* y, const void* dy, void* dqkv, int n,
-                        int L, int heads, int d_head, const DropCfg& drop, hipStream_t stream) {
+                        int L, int heads, int d_head, const DropCfg& drop, hipStream_t stream, const uint32_t* tmask,
+                        const float* bias) {
   if (!nr_attn_mfma_supported(L, d_head)) return -1;
   AttnMArgs a;
+  a.tmask = nullptr; a.bias = nullptr;
   a.qkv = qkv; a.mask = mask; a.y = y; a.dy = dy; a.dqkv = dqkv;
   a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;
   a.scale = 1.0f / sqrtf((float)d_head);
@@ -1321,6 +1382,13 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   const bool fast = dtype == NR_BF16 && a.vec && !old_path;
   if (L > 32 && !fast) return -1;   // caller falls back to the LDS/VALU kernels
   NrProfScope ps(stream, "attn_mfma_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? "bwd" : "fwd", dtype == NR_BF16 ? "bf16" : "f32", n, L, heads, d_head);
+  if (tmask != nullptr) {
+    if (!(fast && L <= 32 && bias != nullptr)) {
+      nr_set_error("attention: padding-token substitution needs the bf16 panel kernels (L <= 32, aligned tensors)");
+      return NR_ERR_ARG;
+    }
+    a.tmask = tmask; a.bias = bias;
+  }
   if (fast) return b16::launch(bwd, a, stream);
   return dtype == NR_BF16 ? launch_t<bf16_t>(bwd, a, stream) : launch_t<float>(bwd, a, stream);
 }

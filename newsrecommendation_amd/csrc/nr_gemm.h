@@ -53,9 +53,12 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
 int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, int M, int K, hipStream_t stream);
 // ws: int32 [2*M + 4] -> ws[0] = number of rows with ids[m*stride] != 0, ws[4 ..] their row numbers, ws[4 + M ..] their ids
 int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* ws, hipStream_t stream);
-// forward flavour: ws int32 [3*M + 4] (adds ws[1] = dead count, ws[2] = "table row 0 is not zero", ws[4+2M ..] dead rows)
-int nr_launch_compact_rows_fwd(const int32_t* ids, int M, const void* table_row0, int cols, int32_t* ws, hipStream_t stream);
+// forward flavour: ws int32 [3*M + n + 4] (adds ws[1] = dead count, ws[2] = "table row 0 is not zero", ws[4+2M ..] dead rows,
+// ws[4+3M ..] per-sequence live-token bit masks when L <= 32)
+int nr_launch_compact_rows_fwd(const int32_t* ids, int M, int n, int L, const void* table_row0, int cols, int32_t* ws,
+                               hipStream_t stream);
+// tmask (optional, with L): rows of sequences whose live-token mask is 0 are skipped (the attention kernels cover them)
 int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_t* rows, const int32_t* count, int max_rows,
-                        hipStream_t stream);
+                        const uint32_t* tmask, int L, hipStream_t stream);
 int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db,
                       int M, int N, int K, int Nstore, int Kstore, hipStream_t stream);

@@ -1673,7 +1673,8 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const int32_t* __rest
 // qkv rows of padding tokens: x = 0 there, so the projection is the bias itself.  A thread owns one 16-byte column chunk
 // (its bias values are converted once); a workgroup walks batches of 64 row numbers staged through LDS.
 __global__ __launch_bounds__(256) void bias_rows_kernel(bf16_t* __restrict__ C, int ldc, int N, const float* __restrict__ bias,
-                                                        const int32_t* __restrict__ rows, const int32_t* __restrict__ count) {
+                                                        const int32_t* __restrict__ rows, const int32_t* __restrict__ count,
+                                                        const uint32_t* __restrict__ tmask, int L) {
   __shared__ int srow[64];
   const int cpr = N / 8, n = *count, tid = threadIdx.x;
   for (int c0 = 0; c0 < cpr; c0 += 256) {
@@ -1683,7 +1684,12 @@ __global__ __launch_bounds__(256) void bias_rows_kernel(bf16_t* __restrict__ C, 
     for (int e = 0; e < 8; ++e) o.h[e] = (bf16_t)((bias && c < cpr) ? bias[c * 8 + e] : 0.f);
     for (int r0 = blockIdx.x * 64; r0 < n; r0 += gridDim.x * 64) {
       __syncthreads();
-      if (tid < 64) srow[tid] = r0 + tid < n ? rows[r0 + tid] : -1;
+      if (tid < 64) {
+        int r = r0 + tid < n ? rows[r0 + tid] : -1;
+        // sequences made of padding tokens only are handled inside the attention kernels: their rows stay unwritten
+        if (r >= 0 && tmask != nullptr && tmask[r / L] == 0) r = -1;
+        srow[tid] = r;
+      }
       __syncthreads();
       if (c < cpr) {
 #pragma unroll 8
@@ -1694,6 +1700,19 @@ __global__ __launch_bounds__(256) void bias_rows_kernel(bf16_t* __restrict__ C, 
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void title_mask_kernel(const int32_t* __restrict__ ids, int n, int L, const int32_t* __restrict__ all_live,
+                                                         uint32_t* __restrict__ tmask) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t m = 0;
+  if (*all_live != 0) {
+    m = 0xffffffffu;
+  } else {
+    for (int t = 0; t < L; ++t) m |= (ids[(size_t)i * L + t] != 0 ? 1u : 0u) << t;
+  }
+  tmask[i] = m;
 }
 
 __global__ void row0_flag_kernel(const bf16_t* __restrict__ row0, int cols, int32_t* __restrict__ flag) {
@@ -1713,24 +1732,29 @@ int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* w
   return NR_OK;
 }
 
-// Forward flavour: ws int32 [3*M + 4]; ws[2] = 1 when row 0 of the (bf16) table is not all zero -> every row live.
-int nr_launch_compact_rows_fwd(const int32_t* ids, int M, const void* table_row0, int cols, int32_t* ws, hipStream_t stream) {
-  NR_CHECK_ARG(ids != nullptr && ws != nullptr && M > 0 && table_row0 != nullptr, "compact_rows_fwd: bad arguments");
+// Forward flavour: ws int32 [3*M + n + 4]; ws[2] = 1 when row 0 of the (bf16) table is not all zero -> every row live;
+// ws[4 + 3M + i] = bit mask of sequence i (L <= 32): bit t set = token t is live.
+int nr_launch_compact_rows_fwd(const int32_t* ids, int M, int n, int L, const void* table_row0, int cols, int32_t* ws,
+                               hipStream_t stream) {
+  NR_CHECK_ARG(ids != nullptr && ws != nullptr && M > 0 && table_row0 != nullptr && n * L == M, "compact_rows_fwd: bad arguments");
   NR_CHECK_HIP(hipMemsetAsync(ws, 0, 4 * sizeof(int32_t), stream));
   NrProfScope ps(stream, "compact_rows[M=%d]", M);
   hipLaunchKernelGGL(row0_flag_kernel, dim3(1), dim3(256), 0, stream, (const bf16_t*)table_row0, cols, ws + 2);
+  if (L <= 32)
+    hipLaunchKernelGGL(title_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ids, n, L, (const int32_t*)(ws + 2),
+                       reinterpret_cast<uint32_t*>(ws + 4 + 3 * (size_t)M));
   hipLaunchKernelGGL(compact_rows_kernel<true>, dim3((M + 1023) / 1024), dim3(256), 0, stream, ids, 1, M, ws, (const int32_t*)(ws + 2));
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
 
 int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_t* rows, const int32_t* count, int max_rows,
-                        hipStream_t stream) {
+                        const uint32_t* tmask, int L, hipStream_t stream) {
   NR_CHECK_ARG(N % 8 == 0 && ldc % 8 == 0, "bias_rows: N=%d / ldc=%d must be multiples of 8", N, ldc);
   NrProfScope ps(stream, "bias_rows[max=%d,N=%d]", max_rows, N);
   size_t grid = ((size_t)max_rows + 63) / 64;
   if (grid > 256 * 8) grid = 256 * 8;
-  hipLaunchKernelGGL(bias_rows_kernel, dim3((unsigned)grid), dim3(256), 0, stream, (bf16_t*)C, ldc, N, bias, rows, count);
+  hipLaunchKernelGGL(bias_rows_kernel, dim3((unsigned)grid), dim3(256), 0, stream, (bf16_t*)C, ldc, N, bias, rows, count, tmask, L);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }

@@ -129,7 +129,7 @@ class MHSAFunction(Function):
         Kp = round_up(d_model, ch)
         x_rows = torch.empty(n * L, Kp, dtype=torch_dtype(code), device=dev) if keep_rows else None
         # scratch for the device-side compaction of non-padding rows (forward: live rows, their ids, padding rows)
-        row_ws = torch.empty(3 * n * L + 4, dtype=torch.int32, device=dev) if keep_rows and code == _lib.NR_BF16 else None
+        row_ws = torch.empty(3 * n * L + n + 4, dtype=torch.int32, device=dev) if keep_rows and code == _lib.NR_BF16 else None
         d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=d_head, dtype=code,
                           src_kind=NR_SRC_GATHER if gather else NR_SRC_DENSE, x=ptr(src), ldx=ldx, ids=ptr(ids),
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
@@ -140,7 +140,7 @@ class MHSAFunction(Function):
         qkv = None if (fused and not need_bwd) else torch.empty(n * L, 3 * N, dtype=torch_dtype(code), device=dev)
         check(_lib.lib().nr_mhsa_fwd(C.byref(d), ptr(qkv), ptr(y), _stream()), "nr_mhsa_fwd")
         ctx.cfg, ctx.dims = cfg, (n, L, N, d_model, heads, d_head, ldx, gather)
-        ctx.row_ws = row_ws if ctx.needs_input_grad[0] else None     # the table-gradient GEMM reuses the compaction
+        ctx.row_ws = row_ws      # the backward attention and the table-gradient GEMM reuse the compaction
         ctx.save_for_backward(src, ids, mask_c, w_p, b_p, wcat, qkv, x_rows)
         return y
 
@@ -157,15 +157,15 @@ class MHSAFunction(Function):
         dw = torch.zeros(3 * N, d_model, dtype=torch.float32, device=dev)
         db = torch.zeros(3 * N, dtype=torch.float32, device=dev)
         need_x = ctx.needs_input_grad[0]
-        dx = dtable = w_t = row_ws = None
-        ws_ready = False
+        dx = dtable = w_t = None
+        row_ws = getattr(ctx, "row_ws", None)          # what the forward compacted (padding rows of qkv were never written)
+        ws_ready = row_ws is not None
         if need_x:
             w_t = pack(wcat, code, transpose=True)                     # [d_model, 3N]
             if gather:
                 dtable = torch.zeros(cfg["table_shape"], dtype=torch.float32, device=dev)
-                row_ws, ws_ready = ctx.row_ws, ctx.row_ws is not None
                 if row_ws is None:
-                    row_ws = torch.empty(3 * n * L + 4, dtype=torch.int32, device=dev)     # live-row compaction scratch
+                    row_ws = torch.empty(3 * n * L + n + 4, dtype=torch.int32, device=dev)     # live-row compaction scratch
             else:
                 dx = torch.empty(n, L, ldx, dtype=torch_dtype(code), device=dev)
         d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=d_head, dtype=code,
