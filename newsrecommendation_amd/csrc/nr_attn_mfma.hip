@@ -190,7 +190,7 @@ template <typename T>
 __global__ __launch_bounds__(AW * 64) void attn_mfma_fwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int IMG = WaveLds<T>::IMG;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   T* base = reinterpret_cast<T*>(smem) + (size_t)wid * 3 * IMG;
   T* sQ = base;
   T* sK = base + IMG;
@@ -279,7 +279,7 @@ template <typename T>
 __global__ __launch_bounds__(AW * 64) void attn_mfma_bwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int IMG = WaveLds<T>::IMG;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   T* base = reinterpret_cast<T*>(smem) + (size_t)wid * 7 * IMG;
   T* sQ = base;
   T* sK = base + IMG;
@@ -911,7 +911,7 @@ __device__ __forceinline__ int clampL(int L, int rb) { return min(32, max(0, L -
 
 __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bf16_t* base = reinterpret_cast<bf16_t*>(smem) + (size_t)wid * 7 * IMG;
   bf16_t *sQ = base, *sK = base + 2 * IMG, *sV = base + 4 * IMG, *sO = base + 6 * IMG;
   float* sMask = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + (size_t)AW * 7 * IMG) + wid * 64;
@@ -986,7 +986,7 @@ __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
 
 __global__ __launch_bounds__(AW * 64) void bwd64_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bf16_t* base = reinterpret_cast<bf16_t*>(smem) + (size_t)wid * 9 * IMG;
   bf16_t *sQ = base, *sK = base + 2 * IMG, *sV = base + 4 * IMG, *sG = base + 6 * IMG, *sO = base + 8 * IMG;
   float* sF = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + (size_t)AW * 9 * IMG) + wid * 256;

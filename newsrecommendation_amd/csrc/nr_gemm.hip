@@ -274,7 +274,7 @@ __global__ __launch_bounds__(NTHR) void gemm_nt_kernel(RowSrc A, const T* __rest
   const int tm = (local / tilesN) * 8 + xcd, tn = local % tilesN;
   if (tm >= tilesM) return;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
   // bf16 outputs: operand roles are swapped so that a lane owns 4 consecutive output columns; the tile goes
   // through a bf16 LDS image (one 8-byte write per MFMA tile) and leaves as 16-byte row-contiguous stores.
   constexpr bool DIRECT = (sizeof(T) == 2) && (EPI != EPI_SCATTER);
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_kernel(const T* __restrict__ dC,
   const int mbeg = blockIdx.y * rows_per_split;
   const int mend = min(M, mbeg + rows_per_split);
   if (mbeg >= mend) return;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
   const bool do_db = (db != nullptr) && (tk == 0);
 
   constexpr bool IS_BF16 = (sizeof(T) == 2);
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn2_kernel(const bf16_t* __restrict
   const int n0 = tn * TBN, k0 = tk * TBK;
   const int mbeg = split * rps, mend = min(M, mbeg + rps);
   if (mbeg >= mend) return;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
   const bool do_db = (db != nullptr) && (tk == 0);
 
   constexpr int NA = TBM * 16 / NTHR, NB = (TBM * 20 + NTHR - 1) / NTHR;
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(WTHR) void gemm_nt_wide_kernel(const bf16_t* __rest
   bf16_t* sB = sA + 2 * BM * SK;                  // [2][WBN][SK]
   float* sC = reinterpret_cast<float*>(smem);     // epilogue: [32][SCW]
   const int m0 = blockIdx.x * BM;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, wm = wid >> 1, wn = wid & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
 
   uint4 ra, rb[NCB];
   auto gload = [&](int k0) {
@@ -1633,7 +1633,7 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const int32_t* __rest
   constexpr int RPT = 4;                                  // 1024 rows per workgroup: 4 batches of 256, order preserved
   __shared__ int wave_cnt[RPT][4];
   __shared__ int base, dbase;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row0 = blockIdx.x * 256 * RPT;
   const bool keep_all = all_live != nullptr && *all_live != 0;
   int id[RPT];

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, 
   constexpr int CH = ChunkOf<T>::CH;
   __shared__ float sS[64];
   __shared__ float sRed[POOL_RED_FLOATS];
-  const int seq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int seq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t row0 = (size_t)seq * L;
   for (int l = wid; l < L; l += 4) {
     const float p = wave_row_dot<T>(e + (row0 + l) * q, w2, q / CH, lane);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
   __shared__ float sDA[64];
   __shared__ float sDS[64];
   __shared__ float sRed[POOL_RED_FLOATS];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qc = q / CH;                       // chunks per e row (<= 256: q <= 1024)
   const int nrg = 256 / qc, cx = tid % qc, rg = tid / qc;
   float accw[4] = {0.f, 0.f, 0.f, 0.f};        // dw2 columns tid, tid+256, ...
@@ -569,7 +569,7 @@ int nr_pad_blend_fwd(const float* x, const float* mask, const float* pad, void* 
 int nr_pad_blend_bwd(const void* dout, const float* mask, float* dx, float* dpad, int n, int L, int N, int dtype,
                      nr_stream_t stream) {
   NR_CHECK_ARG(dout && dx && n > 0 && L > 0 && N > 0, "pad_blend_bwd: null/empty");
-  const int rows = n * L, rpb = 16;   // 16 rows per workgroup: enough workgroups to fill the chip at the user level (25 600 rows)
+  const int rows = n * L, rpb = 64;
   hipStream_t s = (hipStream_t)stream;
   NrProfScope ps(s, "pad_blend_bwd[n=%d,L=%d,N=%d]", n, L, N);
   if (dtype == NR_BF16)
