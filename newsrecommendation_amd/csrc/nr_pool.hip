@@ -126,7 +126,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ e,
                                                        const float* __restrict__ w2, const float* __restrict__ alpha,
                                                        const float* __restrict__ g, int ld_g, T* __restrict__ dpre,
-                                                       float* __restrict__ partial, int n, int L, int N, int q) {
+                                                       float* __restrict__ partial, int n, int L, int N, int q, int spb) {
   constexpr int CH = ChunkOf<T>::CH;
   __shared__ float sDA[64];
   __shared__ float sDS[64];
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
   float w2c[CH];
 #pragma unroll
   for (int k = 0; k < CH; ++k) w2c[k] = w2[cx * CH + k];
-  for (int s = 0; s < POOL_SPB; ++s) {
-    const int seq = blockIdx.x * POOL_SPB + s;
+  for (int s = 0; s < spb; ++s) {
+    const int seq = blockIdx.x * spb + s;
     if (seq >= n) break;
     const size_t row0 = (size_t)seq * L;
     const float* gr = g + (size_t)seq * ld_g;
@@ -459,7 +459,10 @@ int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float
   return NR_OK;
 }
 
-int nr_pool_partial_rows(int n) { return (n + POOL_SPB - 1) / POOL_SPB; }
+// sequences per workgroup: 8 at the news level; fewer when there are few sequences (user level, n = batch), so that the
+// grid still covers the chip.  The caller's partial buffer holds ceil(n / 8) rows at least and n rows at most.
+static int pool_spb(int n) { return n >= 8192 ? POOL_SPB : (n >= 2048 ? 2 : 1); }
+int nr_pool_partial_rows(int n) { const int spb = pool_spb(n); return (n + spb - 1) / spb; }
 
 int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float* w2, const float* alpha, const float* g,
                             int ld_g, void* dpre, float* partial, float* dw2, float* db2, int n, int L, int N, int q,
@@ -471,9 +474,9 @@ int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float
   const int nb = nr_pool_partial_rows(n);
   NrProfScope ps(s, "pool_core_bwd[n=%d,L=%d,N=%d,q=%d]", n, L, N, q);
   if (dtype == NR_BF16)
-    hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)e, w2, alpha, g, ld_g, (bf16_t*)dpre, partial, n, L, N, q);
+    hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)e, w2, alpha, g, ld_g, (bf16_t*)dpre, partial, n, L, N, q, pool_spb(n));
   else
-    hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)e, w2, alpha, g, ld_g, (float*)dpre, partial, n, L, N, q);
+    hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)e, w2, alpha, g, ld_g, (float*)dpre, partial, n, L, N, q, pool_spb(n));
   NR_CHECK_LAUNCH();
   const int ysplit = nb >= 512 ? 32 : (nb >= 64 ? 8 : 1);
   hipLaunchKernelGGL(colsum_kernel, dim3((q + 63) / 64, ysplit), dim3(256), 0, s, partial, nb, q, q + 1, dw2);

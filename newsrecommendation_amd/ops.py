@@ -227,7 +227,7 @@ class PoolFunction(Function):
         g = g.contiguous().float()
         w1_t = pack(w1, code, transpose=True) if ctx.needs_input_grad[0] else None    # [N, q]
         dpre = torch.empty_like(e)
-        partial = torch.empty(((n + 7) // 8) * (q + 1), dtype=torch.float32, device=dev)
+        partial = torch.empty(n * (q + 1), dtype=torch.float32, device=dev)     # one row per workgroup (<= n of them)
         dw1 = torch.zeros(q, N, dtype=torch.float32, device=dev)
         db1 = torch.zeros(q, dtype=torch.float32, device=dev)
         dw2 = torch.zeros(q, dtype=torch.float32, device=dev)
