@@ -241,6 +241,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const T* __restrict__ do
   const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
   for (int c = threadIdx.x; c < N; c += 256) {
     float acc = 0.f;
+#pragma unroll 8
     for (int r = r0; r < r1; ++r) {
       const float d = (float)dout[(size_t)r * N + c];
       const float m = mask ? mask[r] : 1.f;
@@ -572,7 +573,7 @@ int nr_pad_blend_fwd(const float* x, const float* mask, const float* pad, void* 
 int nr_pad_blend_bwd(const void* dout, const float* mask, float* dx, float* dpad, int n, int L, int N, int dtype,
                      nr_stream_t stream) {
   NR_CHECK_ARG(dout && dx && n > 0 && L > 0 && N > 0, "pad_blend_bwd: null/empty");
-  const int rows = n * L, rpb = 64;
+  const int rows = n * L, rpb = 32;
   hipStream_t s = (hipStream_t)stream;
   NrProfScope ps(s, "pad_blend_bwd[n=%d,L=%d,N=%d]", n, L, N);
   if (dtype == NR_BF16)
