@@ -91,7 +91,8 @@ __device__ __forceinline__ uint4 load_rows_chunk(const RowSrc& s, int m, int k, 
     col = d;
   }
   c.u = *reinterpret_cast<const uint4*>(p);
-  if (s.drop.thresh) drop_chunk<T>(c, s.drop, eidx, col, s.Dtrue);
+  // an all-zero chunk (padding token) stays zero whatever the mask says: no hashing
+  if (s.drop.thresh && (c.u.x | c.u.y | c.u.z | c.u.w) != 0u) drop_chunk<T>(c, s.drop, eidx, col, s.Dtrue);
   return c.u;
 }
 
@@ -147,7 +148,7 @@ __device__ __forceinline__ uint4 load_ctx_chunk(const RowSrc& s, const RowCtx<T>
     eidx = c.e0 + (uint32_t)k;
   }
   ch.u = *reinterpret_cast<const uint4*>(p);
-  if (s.drop.thresh) drop_chunk<T>(ch, s.drop, eidx, col, s.Dtrue);
+  if (s.drop.thresh && (ch.u.x | ch.u.y | ch.u.z | ch.u.w) != 0u) drop_chunk<T>(ch, s.drop, eidx, col, s.Dtrue);
   return ch.u;
 }
 
