@@ -1621,6 +1621,29 @@ int launch_tn_d(const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, fl
 
 }  // namespace
 
+// im2col rows of the k=3 convolution, [M, 3*Dp]: row m = [x[m-1] | x[m] | x[m+1]] inside its title (zeros across the
+// title borders).  One thread reads and hashes a source chunk x[m][d..] ONCE and stores it into the (up to) three rows
+// that contain it; the border zeros are written by the token that sits at the border.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3_materialize_kernel(RowSrc A, T* __restrict__ out, int ldo, int M) {
+  constexpr int CH = 16 / (int)sizeof(T);
+  const int Dp = A.ld, cpr = Dp / CH, T_ = A.Tlen;
+  const size_t total = (size_t)M * cpr;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(u / cpr), d = (int)(u - (size_t)m * cpr) * CH;
+    const int blk = m / T_, t = m - blk * T_;
+    // centre tap (k = Dp + d) of row m is x[m][d] itself
+    const uint4 v = load_rows_chunk<T, ROWS_IM2COL3>(A, m, Dp + d, M, 3 * Dp);
+    T* o = out + (size_t)m * ldo + d;
+    *reinterpret_cast<uint4*>(o + Dp) = v;                                       // row m, tap 1
+    if (t + 1 < T_) *reinterpret_cast<uint4*>(o + ldo) = v;                      // row m+1, tap 0
+    else *reinterpret_cast<uint4*>(o + 2 * Dp) = zero;                           // last token: its own tap 2 is empty
+    if (t > 0) *reinterpret_cast<uint4*>(o - ldo + 2 * Dp) = v;                  // row m-1, tap 2
+    else *reinterpret_cast<uint4*>(o) = zero;                                    // first token: its own tap 0 is empty
+  }
+}
+
 // Row compaction for the table-gradient GEMM: rows with token id 0 add nothing (padding_idx), and in a MIND-shaped
 // batch they are ~70 % of all rows (zero-padded title tails, empty history slots).  One pass, no host round trip:
 // 256 rows per workgroup, order kept inside a workgroup, workgroups append through one atomic counter.
@@ -1768,10 +1791,13 @@ int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, i
   size_t grid = (total + 255) / 256;
   if (grid > 256 * 32) grid = 256 * 32;
   if (A.kind == ROWS_IM2COL3) {
+    NR_CHECK_ARG(K == 3 * A.ld && A.ld % ch == 0, "rows_materialize: im2col rows are [M, 3*Dp]");
+    size_t g3 = ((size_t)M * (A.ld / ch) + 255) / 256;
+    if (g3 > 256 * 32) g3 = 256 * 32;
     if (dtype == NR_BF16)
-      hipLaunchKernelGGL((rows_materialize_kernel<bf16_t, ROWS_IM2COL3>), dim3((unsigned)grid), dim3(256), 0, stream, A, (bf16_t*)out, ldo, M, K);
+      hipLaunchKernelGGL(im2col3_materialize_kernel<bf16_t>, dim3((unsigned)g3), dim3(256), 0, stream, A, (bf16_t*)out, ldo, M);
     else
-      hipLaunchKernelGGL((rows_materialize_kernel<float, ROWS_IM2COL3>), dim3((unsigned)grid), dim3(256), 0, stream, A, (float*)out, ldo, M, K);
+      hipLaunchKernelGGL(im2col3_materialize_kernel<float>, dim3((unsigned)g3), dim3(256), 0, stream, A, (float*)out, ldo, M);
   } else if (dtype == NR_BF16)
     hipLaunchKernelGGL((rows_materialize_kernel<bf16_t, ROWS_GATHER>), dim3((unsigned)grid), dim3(256), 0, stream, A, (bf16_t*)out, ldo, M, K);
   else
