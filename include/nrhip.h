@@ -226,6 +226,8 @@ int nr_score_eval(const float* news_vecs, int ld_news, const int32_t* cand_ids, 
  * bracketed by hipEventRecord on the launch stream.  nr_prof_collect waits for the recorded events,
  * writes one line per label "label<TAB>launches<TAB>total_ms\n" into buf (host), clears the log and
  * returns the number of bytes written (or a negative NR_ERR_* code).                          */
+/* on = 1: every launch; on = 2: only launches that work on >= 65 536 rows (a pair of event records costs ~3 us of
+ * stream time, which adds up over the ~60 small launches of a step); on = 0: off.               */
 int nr_prof_enable(int on);
 int nr_prof_collect(char* buf, size_t n);
 

@@ -134,7 +134,8 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"libnrhip {what} failed (code {rc}): {last_error()}")
 
 
-def prof_enable(on: bool) -> None:
+def prof_enable(on) -> None:
+    """False/0 off, True/1 every launch, 2 only launches over >= 65 536 rows."""
     check(lib().nr_prof_enable(int(on)), "nr_prof_enable")
 
 

@@ -1,6 +1,7 @@
 // extern "C" entry points of libnrhip that compose several launches (see include/nrhip.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "nr_gemm.h"
@@ -35,7 +36,22 @@ struct ProfEntry { std::string label; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 std::vector<ProfEntry> g_prof_log;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+int g_prof_mode = 1;   // 1: every launch; 2: only launches over >= 65 536 rows (the label carries M= / Mmax= / n=,L=)
+// rows a launch works on, read off its label; -1 when the label has no such field
+long prof_label_rows(const char* label) {
+  const char* p;
+  if ((p = strstr(label, "Mmax=")) != nullptr) return atol(p + 5);
+  if ((p = strstr(label, "M=")) != nullptr) return atol(p + 2);
+  if ((p = strstr(label, "max=")) != nullptr) return atol(p + 4);
+  if ((p = strstr(label, "n=")) != nullptr) {
+    const long n = atol(p + 2);
+    const char* q = strstr(p, "L=");
+    return q != nullptr ? n * atol(q + 2) : n;
+  }
+  return -1;
+}
 int prof_begin(const char* label, hipStream_t s) {
+  if (g_prof_mode == 2 && prof_label_rows(label) < 65536) return -1;   // a pair of event records costs ~3 us of stream time
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfEntry e;
   e.label = label;
@@ -166,6 +182,7 @@ int nr_version(void) { return 101; }
 
 int nr_prof_enable(int on) {
   g_nr_prof_on = on != 0;
+  g_prof_mode = on == 2 ? 2 : 1;
   return NR_OK;
 }
 
