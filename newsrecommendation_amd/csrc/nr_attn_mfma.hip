@@ -896,10 +896,21 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     }
     // stored straight from the registers: routing dQ/dK/dV through LDS panels like the forward output measured
     // slower here (1.38 vs 1.18 ms)
-    bf16_t* op = dqkv + row0 * N3 + (active ? head : 0) * d;
-    acc_t_to_global<false>(dq, op, N3, Ls, d, lane, nodrop, 0, 0);
-    acc_t_to_global<false>(dk, op + N, N3, Ls, d, lane, nodrop, 0, 0);
-    acc_t_to_global<false>(dv, op + 2 * N, N3, Ls, d, lane, nodrop, 0, 0);
+    {
+      // dQ|dK|dV leave through three [L][AW*d] panels that ALIAS the (now dead) operand images: the workgroup then
+      // stores consecutive 8-byte pieces, 160-byte runs per row and matrix instead of 40-byte head slivers
+      const int ops = AW * d + 8;
+      __syncthreads();                                   // every wave is done reading the images
+      acc_t_to_panel<false>(dq, img0, ops, wid, Ls, d, lane, nodrop, 0, 0);
+      acc_t_to_panel<false>(dk, img0 + 32 * ops, ops, wid, Ls, d, lane, nodrop, 0, 0);
+      acc_t_to_panel<false>(dv, img0 + 64 * ops, ops, wid, Ls, d, lane, nodrop, 0, 0);
+      __syncthreads();
+      bf16_t* op = dqkv + row0 * N3 + it.hg * AW * d;
+      const int hcount = min(AW, a.heads - it.hg * AW);
+      panel_store<PT>(img0, ops, op, N3, pc, hcount);
+      panel_store<PT>(img0 + 32 * ops, ops, op + N, N3, pc, hcount);
+      panel_store<PT>(img0 + 64 * ops, ops, op + 2 * N, N3, pc, hcount);
+    }
     __syncthreads();
   }
 }
