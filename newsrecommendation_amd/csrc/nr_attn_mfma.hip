@@ -775,9 +775,13 @@ template <bool HAS_MASK, int PT, bool SUB>
 __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void bwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR address math
+  // Image block, MATRIX-major: [Q x AW waves | V x AW | K x AW | G x AW].  The output panels of an item are written over
+  // the Q and V images (see the end of the loop) and dirty their zero padding for good; K and G stay clean, and every
+  // product that contracts over the padded head dimension pairs a dirty operand with a clean one (K.Q^T, V.G^T), while
+  // the token-contracting products meet exact zeros of P / dS / G in the padded rows.
   bf16_t* img0 = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* base = img0 + (size_t)wid * 4 * IMG;
-  bf16_t *sQ = base, *sK = base + IMG, *sV = base + 2 * IMG, *sG = base + 3 * IMG;
+  bf16_t *imQ = img0, *imV = img0 + AW * IMG, *imK = img0 + 2 * AW * IMG, *imG = img0 + 3 * AW * IMG;
+  bf16_t *sQ = imQ + wid * IMG, *sK = imK + wid * IMG, *sV = imV + wid * IMG, *sG = imG + wid * IMG;
   float* sF = reinterpret_cast<float*>(img0 + (size_t)AW * 4 * IMG) + wid * 128;
   float *sMask = sF, *sM = sF + 32, *sInv = sF + 64, *sRd = sF + 96;
   const int N = a.N, L = a.L, d = a.d, N3 = 3 * a.N;
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
   bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.dqkv);
   const int h2 = lane >> 5, li = lane & 31;
   const float c1 = a.scale * LOG2E;
-  const Pieces<PT> pc = make_pieces<PT>(tid, L, d, 4);
+  const Pieces<PT> pc = make_pieces<PT>(tid, L, d, 1);    // per matrix the AW head images are adjacent
   zero_images(img0, AW * 4, tid);
   bf16_t* sBias = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(img0 + (size_t)AW * 4 * IMG) + AW * 128);   // SUB: bias [3N] as bf16
   if (SUB)
@@ -820,15 +824,15 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const int Ls = active ? L : 0;
     if (SUB && dead_next) {
       const int hoff = it.hg * AW * d, hcount = min(AW, a.heads - it.hg * AW);
-      panel_put_bias(img0, pc, sBias + hoff, hcount);
-      panel_put_bias(img0 + IMG, pc, sBias + N + hoff, hcount);
-      panel_put_bias(img0 + 2 * IMG, pc, sBias + 2 * N + hoff, hcount);
+      panel_put_bias(imQ, pc, sBias + hoff, hcount);
+      panel_put_bias(imK, pc, sBias + N + hoff, hcount);
+      panel_put_bias(imV, pc, sBias + 2 * N + hoff, hcount);
     } else {
-      panel_put<false>(rq, img0, pc, nodrop, 0, 0);
-      panel_put<false>(rk, img0 + IMG, pc, nodrop, 0, 0);
-      panel_put<false>(rv, img0 + 2 * IMG, pc, nodrop, 0, 0);
+      panel_put<false>(rq, imQ, pc, nodrop, 0, 0);
+      panel_put<false>(rk, imK, pc, nodrop, 0, 0);
+      panel_put<false>(rv, imV, pc, nodrop, 0, 0);
     }
-    panel_put<true>(rg, img0 + 3 * IMG, pc, a.drop, (uint32_t)(row0 * N) + (uint32_t)(it.hg * AW * d), N);
+    panel_put<true>(rg, imG, pc, a.drop, (uint32_t)(row0 * N) + (uint32_t)(it.hg * AW * d), N);
     if (HAS_MASK && lane < 32) sMask[lane] = (lane < Ls) ? a.mask[row0 + lane] : 0.f;
     __syncthreads();
     nx.next(hgroups, stride);
@@ -896,10 +900,10 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     }
     // stored straight from the registers: routing dQ/dK/dV through LDS panels like the forward output measured
     // slower here (1.38 vs 1.18 ms)
-    {
-      // dQ|dK|dV leave through three [L][AW*d] panels that ALIAS the (now dead) operand images: the workgroup then
+    if (3 * 32 * AW * d <= 2 * AW * IMG) {                // d <= 21
+      // dQ|dK|dV leave through three [32][AW*d] panels that ALIAS the (now dead) Q and V images: the workgroup then
       // stores consecutive 8-byte pieces, 160-byte runs per row and matrix instead of 40-byte head slivers
-      const int ops = AW * d + 8;
+      const int ops = AW * d;
       __syncthreads();                                   // every wave is done reading the images
       acc_t_to_panel<false>(dq, img0, ops, wid, Ls, d, lane, nodrop, 0, 0);
       acc_t_to_panel<false>(dk, img0 + 32 * ops, ops, wid, Ls, d, lane, nodrop, 0, 0);
@@ -910,6 +914,11 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       panel_store<PT>(img0, ops, op, N3, pc, hcount);
       panel_store<PT>(img0 + 32 * ops, ops, op + N, N3, pc, hcount);
       panel_store<PT>(img0 + 64 * ops, ops, op + 2 * N, N3, pc, hcount);
+    } else {                                              // wider heads: the panels would not fit into two image groups
+      bf16_t* op = dqkv + row0 * N3 + (active ? head : 0) * d;
+      acc_t_to_global<false>(dq, op, N3, Ls, d, lane, nodrop, 0, 0);
+      acc_t_to_global<false>(dk, op + N, N3, Ls, d, lane, nodrop, 0, 0);
+      acc_t_to_global<false>(dv, op + 2 * N, N3, Ls, d, lane, nodrop, 0, 0);
     }
     __syncthreads();
   }
