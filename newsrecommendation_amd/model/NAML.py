@@ -91,8 +91,9 @@ class Model(torch.nn.Module):
         F = history.shape[-1]
         B, C = candidate.shape[0], 1 + a.npratio
         vecs = self.news_encoder(torch.cat([candidate.reshape(-1, F), history.reshape(-1, F)], dim=0))
-        cand_vecs = vecs[: B * C].reshape(B, C, a.news_dim)
-        hist_vecs = vecs[B * C:].reshape(B, a.user_log_length, a.news_dim)
+        cand_flat, hist_flat = vecs.split([B * C, vecs.shape[0] - B * C], dim=0)     # one cat in backward, no zero fills
+        cand_vecs = cand_flat.reshape(B, C, a.news_dim)
+        hist_vecs = hist_flat.reshape(B, a.user_log_length, a.news_dim)
         user_vec = self.user_encoder(hist_vecs, history_mask)
         loss, score = ops.score_ce(cand_vecs, user_vec, label)
         return loss, score

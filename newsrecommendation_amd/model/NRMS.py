@@ -77,7 +77,8 @@ class Model(torch.nn.Module):
         cand = candidate.reshape(-1, a.num_words_title)
         hist = history.reshape(-1, a.num_words_title)
         # one encoder pass over candidates + history (the reference makes two, src/model/NRMS.py:87,90)
-        if getattr(a, "compact_history", False):
+        compact = getattr(a, "compact_history", False)
+        if compact:
             # Opt-in, beyond the reference: a history slot with mask 0 reaches the loss only through `vec * 0` (pad_doc
             # blend, NRMS.py:59-60) or through attention / pooling weights that the mask zeroes (model_utils.py:28,51),
             # so its news vector and every gradient through it are exactly 0 -- the reference encodes those titles for
@@ -85,11 +86,13 @@ class Model(torch.nn.Module):
             # in training the dropout draws land on different rows (the counters follow the compacted order).
             live = (history_mask.reshape(-1) != 0).nonzero(as_tuple=False).squeeze(1)     # host sync: the count
             vecs = self.news_encoder(torch.cat([cand, hist.index_select(0, live)], dim=0))
-            hist_flat = vecs.new_zeros(hist.shape[0], a.news_dim).index_copy(0, live, vecs[B * C:])
         else:
             vecs = self.news_encoder(torch.cat([cand, hist], dim=0))
-            hist_flat = vecs[B * C:]
-        cand_vecs = vecs[: B * C].reshape(B, C, a.news_dim)
+        # split, not two slices: its backward is one concatenation instead of two zero-filled full-size buffers and an add
+        cand_flat, hist_flat = vecs.split([B * C, vecs.shape[0] - B * C], dim=0)
+        if compact:
+            hist_flat = vecs.new_zeros(hist.shape[0], a.news_dim).index_copy(0, live, hist_flat)
+        cand_vecs = cand_flat.reshape(B, C, a.news_dim)
         hist_vecs = hist_flat.reshape(B, a.user_log_length, a.news_dim)
         user_vec = self.user_encoder(hist_vecs, history_mask)
         loss, score = ops.score_ce(cand_vecs, user_vec, label)

@@ -154,8 +154,8 @@ class MHSAFunction(Function):
         if dy.dtype != torch_dtype(code):
             dy = dy.to(torch_dtype(code))
         dqkv = torch.empty_like(qkv)
-        dw = torch.zeros(3 * N, d_model, dtype=torch.float32, device=dev)
-        db = torch.zeros(3 * N, dtype=torch.float32, device=dev)
+        flat = torch.zeros(3 * N * d_model + 3 * N, dtype=torch.float32, device=dev)     # dw | db, one fill
+        dw, db = flat[:3 * N * d_model].view(3 * N, d_model), flat[3 * N * d_model:]
         need_x = ctx.needs_input_grad[0]
         dx = dtable = w_t = None
         row_ws = getattr(ctx, "row_ws", None)          # what the forward compacted (padding rows of qkv were never written)
@@ -228,10 +228,9 @@ class PoolFunction(Function):
         w1_t = pack(w1, code, transpose=True) if ctx.needs_input_grad[0] else None    # [N, q]
         dpre = torch.empty_like(e)
         partial = torch.empty(n * (q + 1), dtype=torch.float32, device=dev)     # one row per workgroup (<= n of them)
-        dw1 = torch.zeros(q, N, dtype=torch.float32, device=dev)
-        db1 = torch.zeros(q, dtype=torch.float32, device=dev)
-        dw2 = torch.zeros(q, dtype=torch.float32, device=dev)
-        db2 = torch.zeros(1, dtype=torch.float32, device=dev)
+        # one zero fill for the four accumulated gradients (views of a flat buffer; q*N and q are multiples of 4)
+        flat = torch.zeros(q * N + 2 * q + 4, dtype=torch.float32, device=dev)
+        dw1, db1, dw2, db2 = flat[:q * N].view(q, N), flat[q * N:q * N + q], flat[q * N + q:q * N + 2 * q], flat[q * N + 2 * q:q * N + 2 * q + 1]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         d = _lib.PoolDesc(n=n, L=L, N=N, q=q, dtype=code, x=ptr(x), mask=ptr(mask_c), w1=ptr(w1_p), ldw1=w1_p.shape[1],
                           b1=ptr(b1_c), w2=ptr(w2_c), b2=ptr(b2_c))
