@@ -273,7 +273,7 @@ def main():
 
     if rank == 0:
         total = a.batch * world * a.steps
-        out = {"metric": "train impressions/sec @ batch 512, " + a.model, "value": round(total / dt, 1), "unit": "impressions/s",
+        out = {"metric": f"train impressions/sec @ batch {a.batch}, " + a.model, "value": round(total / dt, 1), "unit": "impressions/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": a.model + " train step (fwd+bwd+Adam), MIND-small shapes: title_len=30, history=50, "
