@@ -102,11 +102,13 @@ typedef struct {
                          them back as a dense operand of the weight-gradient GEMM (no second gather / RNG pass);
                          NULL: backward regenerates X from (table, ids, seed_in).                            */
   int ld_rows;
-  int32_t* row_ws;    /* optional scratch, int32 [3*n*L + n + 4] (bf16 gather source only).  Padding tokens (id 0) gather the
+  int32_t* row_ws;    /* optional scratch, int32 [3*n*L + 2*n + n*L/32 + 16] (bf16 gather source only).  Padding tokens (id 0) gather the
                          zero row of the table: nr_mhsa_fwd (when x_rows is given too) compacts the other rows on the
                          device, projects those alone and writes the bias into the rest (if table row 0 is not zero every
                          row is kept); nr_mhsa_bwd compacts again and runs the dX GEMM over the rows that reach the
-                         table gradient.  No host synchronisation.  NULL: every row goes through the GEMMs.       */
+                         table gradient; a pass over dy flags the sequences with a non-zero upstream gradient and the
+                         weight-gradient GEMM contracts only the 32-row slabs that touch one (the rest of dQ|dK|dV is exactly
+                         zero).  No host synchronisation.  NULL: every row goes through the GEMMs.                    */
   int row_ws_ready;   /* nr_mhsa_bwd only: nonzero = row_ws still holds what nr_mhsa_fwd wrote for these ids (reused as is).
                          REQUIRED when nr_mhsa_fwd was given row_ws: on the bf16 title-level path the forward then leaves
                          the qkv rows of all-padding sequences unwritten (the attention kernels substitute the bias), and the

@@ -314,6 +314,18 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
                  "mhsa_bwd: the forward left padding rows of qkv unwritten; qkv / dy / dqkv must be 8-byte aligned");
     tmask = reinterpret_cast<const uint32_t*>(d->row_ws + 4 + 3 * (size_t)M);
   }
+  // Sequences whose upstream gradient dy is exactly zero (history slots the user encoder masks out) get exact zeros in
+  // dQ|dK|dV (dP = dy.V^T = 0, so dS = 0): a pass over dy flags the others, and the weight-gradient GEMM contracts only
+  // the 32-row slabs that touch a flagged sequence.  Scratch: the tail of row_ws (n flags, count, M/32 slab ids).
+  static const bool no_slabs = getenv("NR_NO_SLABS") != nullptr;
+  int32_t* slab_ws = nullptr;
+  if (!no_slabs && d->row_ws != nullptr && d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER && d->x_rows != nullptr && M % 32 == 0 &&
+      M >= 4096 && nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, dqkv) && (((uintptr_t)dy) & 7) == 0 &&
+      nr_gemm_tn_slabs_ok(3 * N, d->ld_rows, M, 3 * N, Kp)) {
+    slab_ws = d->row_ws + 4 + 3 * (size_t)M + d->n;
+    if ((rc = nr_launch_title_flags(dy, d->n, d->L, N, slab_ws, s))) return rc;    // one pass over dy (bf16 [M, N])
+    if ((rc = nr_launch_live_slabs(slab_ws, d->n, d->L, s))) return rc;
+  }
   if ((rc = nr_launch_attn(true, d->dtype, qkv, d->mask, nullptr, dy, dqkv, d->n, d->L, d->heads, d->d_head,
                            nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr)))
     return rc;
@@ -327,7 +339,13 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
   const bool fork = want_dx && side_enabled() && M >= 65536;
   hipStream_t s2 = s;
   if (fork && (rc = side_fork(s, &s2))) return rc;
-  if ((rc = nr_launch_gemm_tn(d->dtype, dqkv, 3 * N, Xs, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model, s))) return rc;
+  if (slab_ws != nullptr) {
+    if ((rc = nr_launch_gemm_tn_slabs(dqkv, 3 * N, d->x_rows, d->ld_rows, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model,
+                                      slab_ws + d->n + 4, slab_ws + d->n, s)))
+      return rc;
+  } else if ((rc = nr_launch_gemm_tn(d->dtype, dqkv, 3 * N, Xs, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model, s))) {
+    return rc;
+  }
   if (want_dx) {
     hipStream_t s = s2;   // the input-gradient GEMM goes to the side stream
     NR_CHECK_ARG(w_qkv_t != nullptr && ldwt >= 3 * N, "mhsa_bwd: w_qkv_t [d_model, >=3N] needed for dx / dtable");

@@ -1366,7 +1366,8 @@ template <int WK, int NI>
 __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __restrict__ dC, int ldc, const bf16_t* __restrict__ X,
                                                             int ldx, float* __restrict__ dW, int ldw, float* __restrict__ db,
                                                             int M, int N, int K, int Nstore, int Kstore, int tilesK, int ntile,
-                                                            int nsplit, int rps) {
+                                                            int nsplit, int rps, const int32_t* __restrict__ slab_list,
+                                                            const int32_t* __restrict__ slab_count) {
   using G = Geo<WK, NI>;
   constexpr int TBN = G::TBN, TBK = G::TBK, NT = G::NT, NW = G::NW, CHA = G::CHA, CH = G::CH, SCW = G::SCW, PA = G::PA, NP = G::NP,
                 STAGE = G::STAGE;
@@ -1381,9 +1382,23 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
   if (split >= nsplit) return;
   const int tn = tile / tilesK, tk = tile % tilesK;
   const int n0 = tn * TBN, k0 = tk * TBK;
-  const int mbeg = split * rps, mend = min(M, mbeg + rps);
-  if (mbeg >= mend) return;
-  const int nk = (mend - mbeg) / TBM;             // exact: M and rps are multiples of TBM (launcher)
+  // Slab mode: only the 32-row slabs listed on the device are contracted (the others are known to be all zero in dC);
+  // the list is divided evenly over the splits and this split's part is staged in LDS.
+  __shared__ int sSlab[1024];
+  const bool slabs = slab_list != nullptr;
+  int mbeg = split * rps, nk;
+  if (slabs) {
+    const int total = *slab_count, per = (total + nsplit - 1) / nsplit, kbeg = split * per;
+    nk = min(per, total - kbeg);
+    if (nk <= 0) return;
+    for (int i = threadIdx.x; i < nk; i += blockDim.x) sSlab[i] = slab_list[kbeg + i];
+    __syncthreads();
+    mbeg = 0;
+  } else {
+    const int mend = min(M, mbeg + rps);
+    if (mbeg >= mend) return;
+    nk = (mend - mbeg) / TBM;                     // exact: M and rps are multiples of TBM (launcher)
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid / WK, wn = wid % WK;
   const bool extra = wid < PX;
@@ -1408,9 +1423,10 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
     }
   }
   auto issue = [&](int stage, int kt) {
+    const size_t sl = slabs ? (size_t)sSlab[kt] : (size_t)kt;
 #pragma unroll
     for (int t = 0; t < PB + 1; ++t)
-      if (t < PB || extra) dma16(src[t] + kt * adv[t], lds0 + stage * STAGE + (pfirst + t) * 1024);
+      if (t < PB || extra) dma16(src[t] + sl * adv[t], lds0 + stage * STAGE + (pfirst + t) * 1024);
   };
   auto wait_stages = [&](int stages) {
     if (extra) {
@@ -1505,7 +1521,7 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
 
 template <int WK, int NI>
 int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
-             int Kstore, hipStream_t stream) {
+             int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr) {
   using G = Geo<WK, NI>;
   const int tilesN = (N + G::TBN - 1) / G::TBN, tilesK = (K + G::TBK - 1) / G::TBK, ntile = tilesN * tilesK;
   // ONE round of resident workgroups (256 CUs x 1 or 2), splits a multiple of the 8 XCDs, >= 16 slabs per split.
@@ -1522,8 +1538,9 @@ int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw
   const int grid = ((nsplit + 7) / 8) * 8 * ntile;
   auto kern = gemm_tn3_kernel<WK, NI>;
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM));
+  if (slab_list != nullptr && (M / TBM + nsplit - 1) / nsplit > 1024) slab_list = nullptr;   // a split's list must fit its LDS stage
   hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::SMEM, stream, (const bf16_t*)dC, ldc, (const bf16_t*)X, ldx, dW, ldw, db, M, N,
-                     K, Nstore, Kstore, tilesK, ntile, nsplit, rps);
+                     K, Nstore, Kstore, tilesK, ntile, nsplit, rps, slab_list, slab_list ? slab_count : nullptr);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -1535,16 +1552,16 @@ bool eligible(int ldc, int ldx, int M, int N, int K) {
   return !off && M % TBM == 0 && M >= 200000 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0 && ldc % 8 == 0 && ldx % 8 == 0;
 }
 int launch(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
-           int Kstore, hipStream_t stream) {
+           int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr) {
   static const int force = [] { const char* e = getenv("NR_TN3_WK"); return e ? atoi(e) : 0; }();
   static const int force_ni = [] { const char* e = getenv("NR_TN3_NI"); return e ? atoi(e) : 0; }();
   const bool wide = force ? force == 4 : (K > 160 && ((K + 319) / 320) * 320 * 100 <= K * 115);
   if (wide) {
     const bool big = force_ni ? force_ni == 8 : N > 256;
-    if (big) return launch_t<4, 8>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
-    return launch_t<4, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+    if (big) return launch_t<4, 8>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count);
+    return launch_t<4, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count);
   }
-  return launch_t<2, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+  return launch_t<2, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count);
 }
 }  // namespace tn3
 
@@ -1841,6 +1858,78 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
   return dtype == NR_BF16 ? launch_nt_d<bf16_t>(A, B, ldb, M, N, K, epi, ep, stream)
                           : launch_nt_d<float>(A, B, ldb, M, N, K, epi, ep, stream);
 }
+
+namespace {
+// 32-row slabs of a [n*L, *] tensor that touch at least one sequence flagged in title_nz, in order; ws[0] = their number
+__global__ __launch_bounds__(256) void live_slabs_kernel(const int32_t* __restrict__ title_nz, int n, int L, int nslab,
+                                                         int32_t* __restrict__ count, int32_t* __restrict__ list) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int s = blockIdx.x * 256 + tid;
+  bool live = false;
+  if (s < nslab) {
+    const int t0 = (32 * s) / L, t1 = min(n - 1, (32 * s + 31) / L);
+    for (int t = t0; t <= t1; ++t) live |= title_nz[t] != 0;
+  }
+  const uint64_t bal = __ballot(live);
+  if (lane == 0) wave_cnt[wid] = __popcll(bal);
+  __syncthreads();
+  if (tid == 0) base = atomicAdd(count, wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+  __syncthreads();
+  if (live) {
+    int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wid; ++w) pos += wave_cnt[w];
+    list[pos] = s;
+  }
+}
+}  // namespace
+
+// title_nz[s] = 1 when any element of the L rows of sequence s in dy [n*L, N] (bf16) is non-zero (-0 counts as zero)
+namespace {
+__global__ __launch_bounds__(256) void title_flags_kernel(const bf16_t* __restrict__ dy, int L, int N, int32_t* __restrict__ title_nz) {
+  const uint4* p = reinterpret_cast<const uint4*>(dy + (size_t)blockIdx.x * L * N);
+  const int chunks = L * N / 8;
+  uint32_t any = 0;
+  for (int c = threadIdx.x; c < chunks; c += 256) {
+    const uint4 v = p[c];
+    any |= (v.x | v.y | v.z | v.w) & 0x7fff7fffu;
+  }
+  __shared__ int flag;
+  if (threadIdx.x == 0) flag = 0;
+  __syncthreads();
+  if (any != 0u) flag = 1;                 // benign race: every writer stores the same value
+  __syncthreads();
+  if (threadIdx.x == 0) title_nz[blockIdx.x] = flag;
+}
+}  // namespace
+int nr_launch_title_flags(const void* dy, int n, int L, int N, int32_t* title_nz, hipStream_t stream) {
+  NR_CHECK_ARG(dy != nullptr && title_nz != nullptr && (L * N) % 8 == 0 && (((uintptr_t)dy) & 15) == 0 && N % 8 == 0,
+               "title_flags: bad arguments");
+  NrProfScope ps(stream, "title_flags[n=%d,L=%d,N=%d]", n, L, N);
+  hipLaunchKernelGGL(title_flags_kernel, dim3(n), dim3(256), 0, stream, (const bf16_t*)dy, L, N, title_nz);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+// ws: int32 [n + 4 + M/32]: ws[0..n) = title_nz (nr_launch_title_flags), ws[n] = slab count, ws[n+4 ..] slab list.
+// The order of the list follows workgroup arrival (arbitrary): the contraction does not care.
+int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream) {
+  const int M = n * L, nslab = M / 32;
+  NR_CHECK_ARG(ws != nullptr && M % 32 == 0, "live_slabs: bad arguments");
+  NR_CHECK_HIP(hipMemsetAsync(ws + n, 0, 4 * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(live_slabs_kernel, dim3((nslab + 255) / 256), dim3(256), 0, stream, ws, n, L, nslab, ws + n, ws + n + 4);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K,
+                            int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream) {
+  NR_CHECK_ARG(tn3::eligible(ldc, ldx, M, N, K), "gemm_tn_slabs: shape not eligible");
+  NrProfScope ps(stream, "gemm_tn3_live[bf16,Mmax=%d,N=%d,K=%d]", M, N, K);
+  return tn3::launch(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count);
+}
+bool nr_gemm_tn_slabs_ok(int ldc, int ldx, int M, int N, int K) { return tn3::eligible(ldc, ldx, M, N, K); }
 
 int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db, int M, int N,
                       int K, int Nstore, int Kstore, hipStream_t stream) {
