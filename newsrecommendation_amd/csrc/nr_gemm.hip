@@ -1903,6 +1903,25 @@ __global__ __launch_bounds__(256) void title_flags_kernel(const bf16_t* __restri
   if (threadIdx.x == 0) title_nz[blockIdx.x] = flag;
 }
 }  // namespace
+// the same for fp32 rows g [n, ld] (one row per sequence)
+namespace {
+__global__ __launch_bounds__(256) void row_flags_f32_kernel(const float* __restrict__ g, int ld, int N, int n, int32_t* __restrict__ nz) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(g + (size_t)row * ld);
+  uint32_t any = 0;
+  for (int c = lane; c < N; c += 64) any |= p[c] & 0x7fffffffu;
+  const uint64_t b = __ballot(any != 0u);
+  if (lane == 0) nz[row] = b != 0ull ? 1 : 0;
+}
+}  // namespace
+int nr_launch_row_flags_f32(const float* g, int ld, int N, int n, int32_t* nz, hipStream_t stream) {
+  NR_CHECK_ARG(g != nullptr && nz != nullptr && n > 0, "row_flags: bad arguments");
+  hipLaunchKernelGGL(row_flags_f32_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, g, ld, N, n, nz);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
 int nr_launch_title_flags(const void* dy, int n, int L, int N, int32_t* title_nz, hipStream_t stream) {
   NR_CHECK_ARG(dy != nullptr && title_nz != nullptr && (L * N) % 8 == 0 && (((uintptr_t)dy) & 15) == 0 && N % 8 == 0,
                "title_flags: bad arguments");

@@ -155,7 +155,8 @@ args = SimpleNamespace(num_words_title=30, user_log_length=50, npratio=4, word_e
                        num_attention_heads=20, news_query_vector_dim=200, user_query_vector_dim=200, drop_rate=0.2,
                        user_log_mask=False, freeze_embedding=False, compute_dtype="bf16")
 g = torch.Generator().manual_seed(3)
-V, B = 5000, 64                                   # 64 * 55 * 30 = 105 600 token rows: above the fork threshold
+import os
+V, B = 5000, int(os.environ.get("NR_TEST_B", "64"))   # 64 * 55 * 30 = 105 600 token rows: above the fork threshold
 table = (torch.randn(V, 300, generator=g) * 0.4).numpy(); table[0] = 0
 m = NRMS.Model(args, table).cuda().train()
 hist = torch.randint(0, V, (B, 50, 30), generator=g, dtype=torch.int32).cuda()
@@ -233,3 +234,30 @@ def test_attention_backward_is_independent_of_what_the_workgroup_computed_before
         assert err <= 3e-2 * ref.abs().max().item() + 1e-2, (name, err, ref.abs().max().item())
     gx = xg.grad.float().cpu()
     assert (gx - xo.grad).abs().max().item() <= 3e-2 * xo.grad.abs().max().item() + 1e-2
+
+
+def test_live_slab_weight_gradients_equal_the_full_contraction():
+    """At full scale (>= 200 000 token rows) the two weight-gradient GEMMs of the news encoder contract only the 32-row
+    slabs that touch a sequence with a non-zero upstream gradient (NR_NO_SLABS=1 switches that off).  Masked history
+    slots have an exactly zero gradient, so both runs must agree up to the order of the fp32 atomics."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(no_slabs):
+        env = dict(os.environ, PYTHONPATH=root, NR_TEST_B="160")     # 160 * 55 * 30 = 264 000 rows
+        env.pop("NR_NO_SLABS", None)
+        if no_slabs:
+            env["NR_NO_SLABS"] = "1"
+        r = subprocess.run([sys.executable, "-c", _SIDE_SCRIPT], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        return json.loads(line[7:])
+
+    a, b = run(True), run(False)
+    assert a["loss"] == b["loss"]
+    for k in a:
+        if k == "loss":
+            continue
+        (s0, a0), (s1, a1) = a[k], b[k]
+        assert abs(a0 - a1) <= 1e-4 * a0 + 1e-6, (k, a0, a1)
+        assert abs(s0 - s1) <= 1e-4 * a0 + 1e-6, (k, s0, s1)
