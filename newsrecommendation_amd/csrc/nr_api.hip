@@ -15,7 +15,7 @@ int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float
                             float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s);
 int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float* w2, const float* alpha, const float* g,
                             int ld_g, void* dpre, float* partial, float* dw2, float* db2, int n, int L, int N, int q,
-                            hipStream_t s);
+                            hipStream_t s, const int32_t* seq_nz = nullptr);
 int nr_launch_cast_rows(int dtype, const float* src, int ld_src, void* dst, int ld_dst, int rows, int cols, hipStream_t s);
 int nr_pool_partial_rows(int n);
 bool nr_mhsa_fused_shape_ok(int L, int heads, int d_head, int d_model, int ldt, int ldw);
@@ -461,21 +461,25 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
   NR_CHECK_ARG(e && alpha && g && dpre && partial && dw1 && db1 && dw2 && db2, "additive_pool_bwd: null operand");
   hipStream_t s = (hipStream_t)stream;
   const int M = d->n * d->L;
-  if ((rc = nr_launch_pool_core_bwd(d->dtype, d->x, e, d->w2, alpha, g, ld_g, dpre, partial, dw2, db2, d->n, d->L, d->N, d->q, s)))
+  // A sequence whose pooled gradient g is exactly zero (a history slot the user encoder masks out) has dA = <g, x> = 0,
+  // so ds = 0 and its dpre rows are exact zeros: the core kernel only writes those zeros for it, and the att_fc1 weight
+  // gradient contracts only the 32-row slabs that touch a sequence with g != 0.  The int scratch (n flags, count, M/32
+  // slab ids) lives in the unused tail of `partial` (its first nr_pool_partial_rows(n) rows are taken).
+  static const bool no_slabs = getenv("NR_NO_SLABS") != nullptr;
+  const size_t used = (size_t)nr_pool_partial_rows(d->n) * (d->q + 1), need = (size_t)d->n + 8 + M / 32;
+  int32_t* ws = nullptr;
+  if (!no_slabs && d->dtype == NR_BF16 && M % 32 == 0 && d->L <= 32 && nr_gemm_tn_slabs_ok(d->q, d->N, M, d->q, d->N) &&
+      used + need + 4 <= (size_t)d->n * (d->q + 1)) {
+    ws = reinterpret_cast<int32_t*>(partial + ((used + 3) / 4) * 4);
+    if ((rc = nr_launch_row_flags_f32(g, ld_g, d->N, d->n, ws, s))) return rc;
+  }
+  if ((rc = nr_launch_pool_core_bwd(d->dtype, d->x, e, d->w2, alpha, g, ld_g, dpre, partial, dw2, db2, d->n, d->L, d->N, d->q, s, ws)))
     return rc;
   RowSrc X = dense_rows(d->x, d->N, d->N);
   const bool fork = dx != nullptr && side_enabled() && M >= 65536;
   hipStream_t s2 = s;
   if (fork && (rc = side_fork(s, &s2))) return rc;
-  // A sequence whose pooled gradient g is exactly zero has dA = <g, x> = 0, so ds = 0 and its dpre rows are exact zeros:
-  // the att_fc1 weight gradient contracts only the 32-row slabs that touch a sequence with g != 0.  The int scratch
-  // (n flags, count, M/32 slab ids) lives in the unused tail of `partial` (its first nr_pool_partial_rows(n) rows are taken).
-  static const bool no_slabs = getenv("NR_NO_SLABS") != nullptr;
-  const size_t used = (size_t)nr_pool_partial_rows(d->n) * (d->q + 1), need = (size_t)d->n + 8 + M / 32;
-  if (!no_slabs && d->dtype == NR_BF16 && M % 32 == 0 && d->L <= 32 && nr_gemm_tn_slabs_ok(d->q, d->N, M, d->q, d->N) &&
-      used + need + 4 <= (size_t)d->n * (d->q + 1)) {
-    int32_t* ws = reinterpret_cast<int32_t*>(partial + ((used + 3) / 4) * 4);
-    if ((rc = nr_launch_row_flags_f32(g, ld_g, d->N, d->n, ws, s))) return rc;
+  if (ws != nullptr) {
     if ((rc = nr_launch_live_slabs(ws, d->n, d->L, s))) return rc;
     if ((rc = nr_launch_gemm_tn_slabs(dpre, d->q, d->x, d->N, dw1, d->N, db1, M, d->q, d->N, d->q, d->N, ws + d->n + 4, ws + d->n, s)))
       return rc;

@@ -126,7 +126,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ e,
                                                        const float* __restrict__ w2, const float* __restrict__ alpha,
                                                        const float* __restrict__ g, int ld_g, T* __restrict__ dpre,
-                                                       float* __restrict__ partial, int n, int L, int N, int q, int spb) {
+                                                       float* __restrict__ partial, int n, int L, int N, int q, int spb,
+                                                       const int32_t* __restrict__ seq_nz) {
   constexpr int CH = ChunkOf<T>::CH;
   __shared__ float sDA[64];
   __shared__ float sDS[64];
@@ -144,6 +145,17 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
     if (seq >= n) break;
     const size_t row0 = (size_t)seq * L;
     const float* gr = g + (size_t)seq * ld_g;
+    if (seq_nz != nullptr && seq_nz[seq] == 0) {
+      // g == 0 for this sequence (a masked history slot): dA = 0, ds = 0, dpre = exact zeros, nothing for dw2 / db2
+      if (rg < nrg)
+        for (int l = rg; l < L; l += nrg) {
+          float o[CH];
+#pragma unroll
+          for (int k = 0; k < CH; ++k) o[k] = 0.f;
+          store_chunk_f<T>(dpre + (row0 + l) * q + cx * CH, o);
+        }
+      continue;
+    }
     for (int l = wid; l < L; l += 4) {
       const float p = wave_row_dot<T>(x + (row0 + l) * N, gr, N / CH, lane);
       if (lane == 0) sDA[l] = p;
@@ -467,7 +479,7 @@ int nr_pool_partial_rows(int n) { const int spb = pool_spb(n); return (n + spb -
 
 int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float* w2, const float* alpha, const float* g,
                             int ld_g, void* dpre, float* partial, float* dw2, float* db2, int n, int L, int N, int q,
-                            hipStream_t s) {
+                            hipStream_t s, const int32_t* seq_nz) {
   NR_CHECK_ARG(L >= 1 && L <= 64, "additive_pool: L=%d must be in [1, 64]", L);
   NR_CHECK_ARG(q <= 1024, "additive_pool: q=%d must be <= 1024", q);
   NR_CHECK_ARG((((uintptr_t)x | (uintptr_t)e | (uintptr_t)dpre | (uintptr_t)g) & 15) == 0 && ld_g % 4 == 0,
@@ -475,9 +487,9 @@ int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float
   const int nb = nr_pool_partial_rows(n);
   NrProfScope ps(s, "pool_core_bwd[n=%d,L=%d,N=%d,q=%d]", n, L, N, q);
   if (dtype == NR_BF16)
-    hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)e, w2, alpha, g, ld_g, (bf16_t*)dpre, partial, n, L, N, q, pool_spb(n));
+    hipLaunchKernelGGL(pool_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)e, w2, alpha, g, ld_g, (bf16_t*)dpre, partial, n, L, N, q, pool_spb(n), seq_nz);
   else
-    hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)e, w2, alpha, g, ld_g, (float*)dpre, partial, n, L, N, q, pool_spb(n));
+    hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)e, w2, alpha, g, ld_g, (float*)dpre, partial, n, L, N, q, pool_spb(n), seq_nz);
   NR_CHECK_LAUNCH();
   const int ysplit = nb >= 512 ? 32 : (nb >= 64 ? 8 : 1);
   hipLaunchKernelGGL(colsum_kernel, dim3((q + 63) / 64, ysplit), dim3(256), 0, s, partial, nb, q, q + 1, dw2);
