@@ -491,6 +491,7 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
     RowSrc P = dense_rows(dpre, d->q, d->q);
     EpiArgs ep = store_epi(dx, d->N, d->dtype, nullptr, 0);
     ep.rowscale = alpha; ep.G = g; ep.ldg = ld_g; ep.L = d->L;
+    ep.seq_nz = ws;                                  // tiles made of zero-gradient sequences only just write zeros
     rc = nr_launch_gemm_nt(d->dtype, P, w1_t, ldw1t, M, d->N, d->q, EPI_POOLBWD, ep, s2);
   }
   if (fork) {

@@ -972,6 +972,22 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
   const int N = min(WBN, Ntot - nbase);
   constexpr int HN = (NT16 + 1) / 2;             // column tiles per wave
   const int tid = threadIdx.x, lane = tid & 63;
+  if (EPI == EPI_POOLBWD && PK && ep.seq_nz != nullptr) {
+    // every sequence of this tile has a zero pooled gradient (and with it zero dpre rows): the output rows are zeros
+    const int t_first = m0 / ep.L, t_last = (min(m0 + DBM, M) - 1) / ep.L;
+    bool live = false;
+    for (int t = t_first + tid; t <= t_last; t += WTHR) live |= ep.seq_nz[t] != 0;
+    if (!__syncthreads_or(live)) {
+      const int cpr = N / 8;                                    // N % 8 == 0 on the packed path
+      if ((N & 7) == 0 && (ep.ldc & 7) == 0 && (nbase & 7) == 0) {
+        for (int u = tid; u < DBM * cpr; u += WTHR) {
+          const int row = u / cpr, c = (u - row * cpr) * 8;
+          if (m0 + row < M) *reinterpret_cast<uint4*>((bf16_t*)ep.C + (size_t)(m0 + row) * ep.ldc + nbase + c) = make_uint4(0, 0, 0, 0);
+        }
+        return;
+      }
+    }
+  }
   const bool compact = (EPI == EPI_SCATTER || EPI == EPI_STORE) && ep.row_count != nullptr;
   if (compact) {
     M = *ep.row_count;                             // rows that survive the compaction (device side, no host sync)
