@@ -1905,17 +1905,26 @@ __global__ __launch_bounds__(256) void live_slabs_kernel(const int32_t* __restri
 namespace {
 __global__ __launch_bounds__(256) void title_flags_kernel(const bf16_t* __restrict__ dy, int L, int N, int32_t* __restrict__ title_nz) {
   const uint4* p = reinterpret_cast<const uint4*>(dy + (size_t)blockIdx.x * L * N);
-  const int chunks = L * N / 8;
-  uint32_t any = 0;
-  for (int c = threadIdx.x; c < chunks; c += 256) {
-    const uint4 v = p[c];
-    any |= (v.x | v.y | v.z | v.w) & 0x7fff7fffu;
-  }
+  const int chunks = L * N / 8, first = min(chunks, 256);
   __shared__ int flag;
   if (threadIdx.x == 0) flag = 0;
   __syncthreads();
-  if (any != 0u) flag = 1;                 // benign race: every writer stores the same value
+  // a sequence with a gradient shows it in its first 4 KB almost always: look there first, scan the rest only if that is zero
+  if ((int)threadIdx.x < first) {
+    const uint4 v = p[threadIdx.x];
+    if (((v.x | v.y | v.z | v.w) & 0x7fff7fffu) != 0u) flag = 1;     // benign race: every writer stores the same value
+  }
   __syncthreads();
+  if (flag == 0) {                                                   // uniform: read after the barrier
+    uint32_t any = 0;
+    for (int c = first + threadIdx.x; c < chunks; c += 256) {
+      const uint4 v = p[c];
+      any |= (v.x | v.y | v.z | v.w) & 0x7fff7fffu;
+    }
+    __syncthreads();                                                 // everyone has read flag == 0 before anyone sets it
+    if (any != 0u) flag = 1;
+    __syncthreads();
+  }
   if (threadIdx.x == 0) title_nz[blockIdx.x] = flag;
 }
 }  // namespace
