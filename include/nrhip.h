@@ -167,7 +167,9 @@ typedef struct {
 /* e: [n*L, q] dtype (tanh output, saved); alpha: [n*L] fp32 (saved); out: fp32, row i at out + i*ld_out. */
 int nr_additive_pool_fwd(const nr_pool_desc* d, void* e, float* alpha, float* out, int ld_out, nr_stream_t stream);
 /* g: fp32 d(out), row i at g + i*ld_g.  w1_t [N, ldw1t] dtype = w1^T.  dpre: workspace [n*L, q] dtype.
- * partial: workspace fp32 [n * (q+1)] (one row per workgroup; small n uses one sequence per workgroup).
+ * partial: workspace fp32 [n * (q+1)] (one row per workgroup; small n uses one sequence per workgroup; at the news level the
+ *          unused tail holds the int32 flags / live-slab list of the sequences whose pooled gradient g is not all zero --
+ *          sequences with g == 0 get exact zeros in dpre / dx and are skipped by the att_fc1 weight gradient).
  * dw1 [q,N], db1 [q], dw2 [q], db2 [1]: accumulated.
  * dx: [n*L, N] dtype (overwritten) or NULL.                                                  */
 int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alpha, const float* g, int ld_g,
