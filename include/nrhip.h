@@ -102,7 +102,7 @@ typedef struct {
                          them back as a dense operand of the weight-gradient GEMM (no second gather / RNG pass);
                          NULL: backward regenerates X from (table, ids, seed_in).                            */
   int ld_rows;
-  int32_t* row_ws;    /* optional scratch, int32 [3*n*L + 2*n + n*L/32 + 16] (bf16 gather source only).  Padding tokens (id 0) gather the
+  int32_t* row_ws;    /* optional scratch, int32 [3*n*L + 3*n + n*L/32 + 32] (bf16 gather source only).  Padding tokens (id 0) gather the
                          zero row of the table: nr_mhsa_fwd (when x_rows is given too) compacts the other rows on the
                          device, projects those alone and writes the bias into the rest (if table row 0 is not zero every
                          row is kept); nr_mhsa_bwd compacts again and runs the dX GEMM over the rows that reach the

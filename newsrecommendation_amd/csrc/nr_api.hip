@@ -9,7 +9,7 @@
 // launchers defined in nr_attn.hip / nr_pool.hip
 int nr_launch_attn(bool bwd, int dtype, const void* qkv, const float* mask, void* y, const void* dy, void* dqkv, int n, int L,
                    int heads, int d_head, const DropCfg& drop, hipStream_t stream, const uint32_t* tmask = nullptr,
-                   const float* bias = nullptr);
+                   const float* bias = nullptr, const int32_t* seq_list = nullptr, const int32_t* seq_count = nullptr);
 bool nr_attn_pad_ok(int dtype, int L, int d_head, const void* p0, const void* p1);
 int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
                             float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s);
@@ -320,15 +320,23 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
   // the 32-row slabs that touch a flagged sequence.  Scratch: the tail of row_ws (n flags, count, M/32 slab ids).
   static const bool no_slabs = getenv("NR_NO_SLABS") != nullptr;
   int32_t* slab_ws = nullptr;
+  int32_t* seq_ws = nullptr;
   if (!no_slabs && d->row_ws != nullptr && d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER && d->x_rows != nullptr && M % 32 == 0 &&
       M >= 4096 && nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, dqkv) && (((uintptr_t)dy) & 7) == 0 &&
       nr_gemm_tn_slabs_ok(3 * N, d->ld_rows, M, 3 * N, Kp)) {
     slab_ws = d->row_ws + 4 + 3 * (size_t)M + d->n;
     if ((rc = nr_launch_title_flags(dy, d->n, d->L, N, slab_ws, s))) return rc;    // one pass over dy (bf16 [M, N])
     if ((rc = nr_launch_live_slabs(slab_ws, d->n, d->L, s))) return rc;
+    static const bool no_skip = getenv("NR_NO_ATTN_SKIP") != nullptr;
+    if (tmask != nullptr && !no_skip) {
+      // the attention backward walks a list that leaves out the all-padding sequences no live slab comes near
+      seq_ws = slab_ws + d->n + 4 + M / 32 + 4;
+      if ((rc = nr_launch_seq_list(slab_ws, tmask, d->n, d->L, seq_ws, s))) return rc;
+    }
   }
   if ((rc = nr_launch_attn(true, d->dtype, qkv, d->mask, nullptr, dy, dqkv, d->n, d->L, d->heads, d->d_head,
-                           nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr)))
+                           nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr, seq_ws ? seq_ws + 4 : nullptr,
+                           seq_ws)))
     return rc;
   // dW_qkv[3N, d_model] += dQKV^T . X ; db += colsum(dQKV).  X: the rows saved by the forward when present.
   RowSrc Xs = A;

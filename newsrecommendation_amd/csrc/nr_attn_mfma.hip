@@ -37,6 +37,8 @@ struct AttnMArgs {
   int vec;            // 1: d % 4 == 0 and all head slices are 4-element aligned -> vector staging / stores
   float scale;
   DropCfg drop;
+  const int32_t* seq_list;   // optional (backward): the kernel walks seq_list[0 .. *seq_count) instead of 0 .. n-1 -- sequences left
+  const int32_t* seq_count;  //   out have exactly zero dQ|dK|dV rows that nothing downstream reads
   const uint32_t* tmask;  // optional [n]: live-token bit mask of each sequence.  0 = padding tokens only: every Q|K|V row
   const float* bias;      //   of that sequence is this bias [3N]; its qkv rows are never written and never read
 };
@@ -800,12 +802,17 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
   ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};
   Panel<PT> rq, rk, rv, rg;
   bool dead_next = false;
+  const bool listed = SUB && a.seq_list != nullptr;
+  const int nseq = listed ? *a.seq_count : a.n;          // sequences to walk
+  int sq_next = 0;                                       // the sequence sitting in the prefetch registers
   auto prefetch = [&](const ItemIter& t) {
-    const size_t r0 = (size_t)t.sb * L;
+    const int sq = listed ? a.seq_list[t.sb] : t.sb;
+    sq_next = sq;
+    const size_t r0 = (size_t)sq * L;
     const int hd = t.hg * AW * d;
     const bf16_t* src = qkv + r0 * N3 + hd;
     const int hcount = min(AW, a.heads - t.hg * AW);
-    dead_next = SUB && a.tmask[t.sb] == 0;
+    dead_next = SUB && a.tmask[sq] == 0;
     if (!dead_next) {
       panel_load(rq, src, N3, pc, hcount);
       panel_load(rk, src + N, N3, pc, hcount);
@@ -816,11 +823,11 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
   __syncthreads();                                       // images zeroed, bias table in LDS
-  prefetch(nx);
-  for (; it.sb < a.n; it.next(hgroups, stride)) {
+  if (nx.sb < nseq) prefetch(nx);
+  for (; it.sb < nseq; it.next(hgroups, stride)) {
     const int head = it.hg * AW + wid;
     const bool active = head < a.heads;
-    const size_t row0 = (size_t)it.sb * L;
+    const size_t row0 = (size_t)sq_next * L;             // taken before the next prefetch overwrites it
     const int Ls = active ? L : 0;
     if (SUB && dead_next) {
       const int hoff = it.hg * AW * d, hcount = min(AW, a.heads - it.hg * AW);
@@ -836,7 +843,7 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     if (HAS_MASK && lane < 32) sMask[lane] = (lane < Ls) ? a.mask[row0 + lane] : 0.f;
     __syncthreads();
     nx.next(hgroups, stride);
-    if (nx.sb < a.n) prefetch(nx);
+    if (nx.sb < nseq) prefetch(nx);
     f32x16 dst;  // dS^T (lane = query i), carries the 1/sqrt(d) factor of dQ and dK
     {
       f32x16 st, dpt;
@@ -1388,10 +1395,10 @@ bool nr_attn_pad_ok(int dtype, int L, int d_head, const void* p0, const void* p1
 
 int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask, void* y, const void* dy, void* dqkv, int n,
                         int L, int heads, int d_head, const DropCfg& drop, hipStream_t stream, const uint32_t* tmask,
-                        const float* bias) {
+                        const float* bias, const int32_t* seq_list, const int32_t* seq_count) {
   if (!nr_attn_mfma_supported(L, d_head)) return -1;
   AttnMArgs a;
-  a.tmask = nullptr; a.bias = nullptr;
+  a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr;
   a.qkv = qkv; a.mask = mask; a.y = y; a.dy = dy; a.dqkv = dqkv;
   a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;
   a.scale = 1.0f / sqrtf((float)d_head);
@@ -1401,13 +1408,16 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   static const bool old_path = getenv("NR_ATTN_OLD") != nullptr;
   const bool fast = dtype == NR_BF16 && a.vec && !old_path;
   if (L > 32 && !fast) return -1;   // caller falls back to the LDS/VALU kernels
-  NrProfScope ps(stream, "attn_mfma_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? "bwd" : "fwd", dtype == NR_BF16 ? "bf16" : "f32", n, L, heads, d_head);
+  // "_live": the backward walks a device-side list of sequences (n is then an upper bound)
+  NrProfScope ps(stream, "attn_mfma_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? (seq_list ? "bwd_live" : "bwd") : "fwd",
+                 dtype == NR_BF16 ? "bf16" : "f32", n, L, heads, d_head);
   if (tmask != nullptr) {
     if (!(fast && L <= 32 && bias != nullptr)) {
       nr_set_error("attention: padding-token substitution needs the bf16 panel kernels (L <= 32, aligned tensors)");
       return NR_ERR_ARG;
     }
     a.tmask = tmask; a.bias = bias;
+    if (bwd && seq_list != nullptr) { a.seq_list = seq_list; a.seq_count = seq_count; }
   }
   if (fast) return b16::launch(bwd, a, stream);
   return dtype == NR_BF16 ? launch_t<bf16_t>(bwd, a, stream) : launch_t<float>(bwd, a, stream);

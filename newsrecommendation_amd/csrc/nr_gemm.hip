@@ -1956,6 +1956,42 @@ int nr_launch_title_flags(const void* dy, int n, int L, int N, int32_t* title_nz
   return NR_OK;
 }
 
+// Sequences the attention backward has to process, in order: everything except the all-padding sequences (tmask == 0)
+// whose own and `margin` neighbours' upstream gradients are zero -- no live 32-row slab overlaps their rows and the
+// table-gradient GEMM never gathers them, so their (exactly zero) dQ|dK|dV rows need not even be written.
+namespace {
+__global__ __launch_bounds__(256) void seq_list_kernel(const int32_t* __restrict__ title_nz, const uint32_t* __restrict__ tmask, int n,
+                                                       int margin, int32_t* __restrict__ count, int32_t* __restrict__ list) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i = blockIdx.x * 256 + tid;
+  bool keep = false;
+  if (i < n) {
+    bool skip = tmask[i] == 0;
+    for (int j = max(0, i - margin); skip && j <= min(n - 1, i + margin); ++j) skip = title_nz[j] == 0;
+    keep = !skip;
+  }
+  const uint64_t bal = __ballot(keep);
+  if (lane == 0) wave_cnt[wid] = __popcll(bal);
+  __syncthreads();
+  if (tid == 0) base = atomicAdd(count, wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+  __syncthreads();
+  if (keep) {
+    int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wid; ++w) pos += wave_cnt[w];
+    list[pos] = i;
+  }
+}
+}  // namespace
+// out: int32 [4 + n]: out[0] = count, out[4 ..] = sequence numbers
+int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream) {
+  NR_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(seq_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, title_nz, tmask, n, 32 / L + 2, out, out + 4);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
 // ws: int32 [n + 4 + M/32]: ws[0..n) = title_nz (nr_launch_title_flags), ws[n] = slab count, ws[n+4 ..] slab list.
 // The order of the list follows workgroup arrival (arbitrary): the contraction does not care.
 int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream) {

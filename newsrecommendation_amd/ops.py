@@ -129,7 +129,7 @@ class MHSAFunction(Function):
         Kp = round_up(d_model, ch)
         x_rows = torch.empty(n * L, Kp, dtype=torch_dtype(code), device=dev) if keep_rows else None
         # scratch for the device-side compaction of non-padding rows (forward: live rows, their ids, padding rows)
-        row_ws = torch.empty(3 * n * L + 2 * n + (n * L) // 32 + 16, dtype=torch.int32, device=dev) if keep_rows and code == _lib.NR_BF16 else None
+        row_ws = torch.empty(3 * n * L + 3 * n + (n * L) // 32 + 32, dtype=torch.int32, device=dev) if keep_rows and code == _lib.NR_BF16 else None
         d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=d_head, dtype=code,
                           src_kind=NR_SRC_GATHER if gather else NR_SRC_DENSE, x=ptr(src), ldx=ldx, ids=ptr(ids),
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
@@ -165,7 +165,7 @@ class MHSAFunction(Function):
             if gather:
                 dtable = torch.zeros(cfg["table_shape"], dtype=torch.float32, device=dev)
                 if row_ws is None:
-                    row_ws = torch.empty(3 * n * L + 2 * n + (n * L) // 32 + 16, dtype=torch.int32, device=dev)     # live-row compaction scratch
+                    row_ws = torch.empty(3 * n * L + 3 * n + (n * L) // 32 + 32, dtype=torch.int32, device=dev)     # live-row compaction scratch
             else:
                 dx = torch.empty(n, L, ldx, dtype=torch_dtype(code), device=dev)
         d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=d_head, dtype=code,
