@@ -108,7 +108,9 @@ typedef struct {
                          row is kept); nr_mhsa_bwd compacts again and runs the dX GEMM over the rows that reach the
                          table gradient; a pass over dy flags the sequences with a non-zero upstream gradient and the
                          weight-gradient GEMM contracts only the 32-row slabs that touch one (the rest of dQ|dK|dV is exactly
-                         zero).  No host synchronisation.  NULL: every row goes through the GEMMs.                    */
+                         zero); all-padding sequences that no live slab comes near are left out of the backward attention altogether
+                         (their dQ|dK|dV rows stay unwritten and are never read).  No host synchronisation.  NULL: every row
+                         goes through the GEMMs.                    */
   int row_ws_ready;   /* nr_mhsa_bwd only: nonzero = row_ws still holds what nr_mhsa_fwd wrote for these ids (reused as is).
                          REQUIRED when nr_mhsa_fwd was given row_ws: on the bf16 title-level path the forward then leaves
                          the qkv rows of all-padding sequences unwritten (the attention kernels substitute the bias), and the
