@@ -147,6 +147,9 @@ typedef struct {
                          taps side by side) here once and runs a dense GEMM on them; a backward given the same buffer
                          reuses them.  NULL: the operand is gathered on the fly inside the GEMMs.               */
   int ld_rows;        /* >= 3*Dp */
+  int32_t* bwd_ws;    /* optional backward scratch, int32 [n + n*T/32 + 16] (bf16, with x_rows): nr_conv1d_k3_bwd flags the
+                         titles whose upstream gradient dy is not all zero and contracts only the 32-row slabs that touch
+                         one (masked history slots have an exactly zero dy).  NULL: every row is contracted.          */
 } nr_conv_desc;
 int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream);
 /* dw_pack [N, 3*Dp] fp32 accumulated (nr_unpack_conv_dw -> [N, D, 3]); db [N] accumulated.

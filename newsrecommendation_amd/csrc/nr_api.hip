@@ -430,6 +430,17 @@ int nr_conv1d_k3_bwd(const nr_conv_desc* d, const void* dy, float* dw_pack, floa
   if (d->x_rows != nullptr) {   // the rows the forward stored
     NR_CHECK_ARG(d->ld_rows >= 3 * d->Dp, "conv1d_bwd: ld_rows=%d must cover %d", d->ld_rows, 3 * d->Dp);
     A = dense_rows(d->x_rows, d->ld_rows, 3 * d->Dp);
+    // titles with an exactly zero upstream gradient (masked history slots) add nothing to dW / db: live slabs only
+    static const bool no_slabs = getenv("NR_NO_SLABS") != nullptr;
+    const int M = d->n * d->T;
+    if (!no_slabs && d->bwd_ws != nullptr && d->dtype == NR_BF16 && M % 32 == 0 && d->T <= 32 && d->N % 8 == 0 &&
+        (((uintptr_t)dy) & 15) == 0 && nr_gemm_tn_slabs_ok(d->N, d->ld_rows, M, d->N, 3 * d->Dp)) {
+      hipStream_t s = (hipStream_t)stream;
+      if ((rc = nr_launch_title_flags(dy, d->n, d->T, d->N, d->bwd_ws, s))) return rc;
+      if ((rc = nr_launch_live_slabs(d->bwd_ws, d->n, d->T, s))) return rc;
+      return nr_launch_gemm_tn_slabs(dy, d->N, d->x_rows, d->ld_rows, dw_pack, 3 * d->Dp, db, M, d->N, 3 * d->Dp, d->N, 3 * d->Dp,
+                                     d->bwd_ws + d->n + 4, d->bwd_ws + d->n, s);
+    }
   }
   return nr_launch_gemm_tn(d->dtype, dy, d->N, A, dw_pack, 3 * d->Dp, db, d->n * d->T, d->N, 3 * d->Dp, d->N, 3 * d->Dp,
                            (hipStream_t)stream);

@@ -361,9 +361,10 @@ class ConvFunction(Function):
             dy = dy.to(torch_dtype(code))
         dwp = torch.zeros(N, 3 * Dp, dtype=torch.float32, device=dev)
         db = torch.zeros(N, dtype=torch.float32, device=dev)
+        bwd_ws = torch.empty(n + (n * T) // 32 + 16, dtype=torch.int32, device=dev) if ctx.x_rows is not None else None
         d = _lib.ConvDesc(n=n, T=T, D=D, Dp=Dp, N=N, dtype=code, table=ptr(table_p), ids=ctx.ids.data_ptr(), ids_stride=stride,
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], w_pack=ptr(w_p), bias=ptr(b_c), x_rows=ptr(ctx.x_rows),
-                          ld_rows=3 * Dp)
+                          ld_rows=3 * Dp, bwd_ws=ptr(bwd_ws))
         check(_lib.lib().nr_conv1d_k3_bwd(C.byref(d), ptr(dy), ptr(dwp), ptr(db), _stream()), "nr_conv1d_k3_bwd")
         dw = torch.empty(N, D, 3, dtype=torch.float32, device=dev)
         check(_lib.lib().nr_unpack_conv_dw(ptr(dwp), N, D, Dp, ptr(dw), _stream()), "nr_unpack_conv_dw")
