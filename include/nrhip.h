@@ -49,6 +49,19 @@ typedef void* nr_stream_t; /* hipStream_t */
 int nr_version(void);
 /* Copies the calling thread's last error message (NUL terminated) into buf; returns its length. */
 int nr_last_error(char* buf, size_t n);
+/* Integer switches of the library (kernel-family selection, debugging): name without the NR_ prefix, e.g.
+ * "NO_SLABS", "SIDE_STREAM", "TN3_ROUNDS" (full list: csrc/nr_common.h, enum NrOpt).  Defaults are the production
+ * configuration; the environment variable NR_<NAME> presets an option once per process.  nr_get_option returns
+ * -1 for an unknown name.  Not thread-synchronised with calls in flight: set options between calls.              */
+/* sizeof of the descriptor structs as this library was compiled: out[0..3] = nr_mhsa_desc, nr_conv_desc, nr_pool_desc,
+ * nr_linear_desc.  A binding compares them with its own layout at load time (ABI drift -> refuse to run).            */
+int nr_abi_sizes(size_t* out, int n);
+int nr_set_option(const char* name, int value);
+int nr_get_option(const char* name);
+
+/* Device: every entry point that takes a stream runs on the device that owns that stream (for the NULL stream: the
+ * device that owns its first pointer argument) -- the library switches the calling thread to it for the duration
+ * of the call (forward runs on the rank's main thread, backward on the autograd engine thread).                   */
 
 /* ---------------------------------------------------------------------------------------
  * Packing: fp32 master parameter -> dtype operand with zero padded leading dimension.
@@ -59,9 +72,10 @@ int nr_last_error(char* buf, size_t n);
 int nr_cast_pad(const float* src, int rows, int cols, int ld_src, void* dst, int ld_dst, int dtype,
                 int transpose, nr_stream_t stream);
 /* Conv1d weight [N, D, 3] (src/model/NAML.py:27-32) -> tap-major GEMM operand [N, 3*Dp]
- * (dst[n, tap*Dp + d] = w[n, d, tap]); unpack is the inverse on an fp32 gradient.          */
+ * (dst[n, tap*Dp + d] = w[n, d, tap]); unpack is the inverse on an fp32 gradient
+ * (accumulate != 0: dw += ..., else dw = ...).                                               */
 int nr_pack_conv_w(const float* w, int N, int D, void* dst, int Dp, int dtype, nr_stream_t stream);
-int nr_unpack_conv_dw(const float* dw_pack, int N, int D, int Dp, float* dw, nr_stream_t stream);
+int nr_unpack_conv_dw(const float* dw_pack, int N, int D, int Dp, float* dw, int accumulate, nr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K1  embedding row gather — nn.Embedding(padding_idx=0) lookup,
@@ -102,7 +116,7 @@ typedef struct {
                          them back as a dense operand of the weight-gradient GEMM (no second gather / RNG pass);
                          NULL: backward regenerates X from (table, ids, seed_in).                            */
   int ld_rows;
-  int32_t* row_ws;    /* optional scratch, int32 [3*n*L + 3*n + n*L/32 + 32] (bf16 gather source only).  Padding tokens (id 0) gather the
+  int32_t* row_ws;    /* optional scratch of nr_mhsa_workspace_bytes(d) bytes (bf16 gather source only).  Padding tokens (id 0) gather the
                          zero row of the table: nr_mhsa_fwd (when x_rows is given too) compacts the other rows on the
                          device, projects those alone and writes the bias into the rest (if table row 0 is not zero every
                          row is kept); nr_mhsa_bwd compacts again and runs the dX GEMM over the rows that reach the
@@ -111,6 +125,7 @@ typedef struct {
                          zero); all-padding sequences that no live slab comes near are left out of the backward attention altogether
                          (their dQ|dK|dV rows stay unwritten and are never read).  No host synchronisation.  NULL: every row
                          goes through the GEMMs.                    */
+  size_t row_ws_bytes; /* size of row_ws in bytes: must be >= nr_mhsa_workspace_bytes(d) when row_ws != NULL (checked) */
   int row_ws_ready;   /* nr_mhsa_bwd only: nonzero = row_ws still holds what nr_mhsa_fwd wrote for these ids (reused as is).
                          REQUIRED when nr_mhsa_fwd was given row_ws: on the bf16 title-level path the forward then leaves
                          the qkv rows of all-padding sequences unwritten (the attention kernels substitute the bias), and the
@@ -122,6 +137,8 @@ typedef struct {
  * Q|K|V on chip; nr_mhsa_fwd_fused(d) returns 1 for such a descriptor, and then qkv may be NULL (inference: the
  * projections are never written to HBM).  On every other path qkv is required.                              */
 int nr_mhsa_fwd_fused(const nr_mhsa_desc* d);
+/* Bytes of row_ws that nr_mhsa_fwd / nr_mhsa_bwd use for this descriptor (depends on n and L only). */
+size_t nr_mhsa_workspace_bytes(const nr_mhsa_desc* d);
 int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream);
 /* dy [n*L, N] dtype.  dqkv: workspace [n*L, 3N] dtype.  w_qkv_t: [Kp, ldwt] dtype = w_qkv^T
  * (nr_cast_pad transpose=1; Kp = d_model rounded up to a chunk; needed only if dx/dtable).
@@ -129,6 +146,24 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream);
  * or NULL; dtable: gather source -> [V, d_model] fp32 accumulated (skips id 0) or NULL.      */
 int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dqkv, const void* w_qkv_t,
                 int ldwt, float* dw_qkv, float* db_qkv, void* dx, float* dtable, nr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The attention core alone -- ScaledDotProductAttention.forward, src/model/model_utils.py:39-55 -- on given
+ * projections.  qkv: [n*L, 3N] dtype, token-major, columns Q | K | V with head h at [h*d_head, (h+1)*d_head) of each
+ * (the layout nr_mhsa_fwd produces; the Python surface class packs the reference's [n, h, L, d] views into it).
+ * mask: [n, L] key-side 0/1 or NULL.  y: [n*L, N] dtype, heads concatenated (src/model/model_utils.py:94).
+ * p_out / seed_out: optional dropout on y (element index m*N + c), 0 = none.
+ * bwd: dqkv [n*L, 3N] dtype = gradient of the three projections given dy [n*L, N].                          */
+int nr_sdpa_fwd(const void* qkv, const float* mask, void* y, int n, int L, int heads, int d_head, int dtype, float p_out,
+                uint32_t seed_out, nr_stream_t stream);
+int nr_sdpa_bwd(const void* qkv, const float* mask, const void* dy, void* dqkv, int n, int L, int heads, int d_head,
+                int dtype, float p_out, uint32_t seed_out, nr_stream_t stream);
+
+/* Index validation (what torch's embedding / cross_entropy raise IndexError for; the kernels themselves trust their
+ * indices).  Counts the entries of ids[i*stride], i < count, outside [0, rows) into *bad (DEVICE int32, accumulated:
+ * zero it first).  The Python layer calls it when ops.CHECK_INDICES is on and raises IndexError.                */
+int nr_check_ids(const int32_t* ids, int count, int stride, int rows, int32_t* bad, nr_stream_t stream);
+int nr_check_labels(const int64_t* label, int count, int classes, int32_t* bad, nr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K4 (+K1,K2 fused)  Conv1d(D, N, kernel_size=3, padding=1) over title tokens,
@@ -147,10 +182,12 @@ typedef struct {
                          taps side by side) here once and runs a dense GEMM on them; a backward given the same buffer
                          reuses them.  NULL: the operand is gathered on the fly inside the GEMMs.               */
   int ld_rows;        /* >= 3*Dp */
-  int32_t* bwd_ws;    /* optional backward scratch, int32 [n + n*T/32 + 16] (bf16, with x_rows): nr_conv1d_k3_bwd flags the
+  int32_t* bwd_ws;    /* optional backward scratch of nr_conv_workspace_bytes(d) bytes (bf16, with x_rows): nr_conv1d_k3_bwd flags the
                          titles whose upstream gradient dy is not all zero and contracts only the 32-row slabs that touch
                          one (masked history slots have an exactly zero dy).  NULL: every row is contracted.          */
+  size_t bwd_ws_bytes; /* size of bwd_ws in bytes, >= nr_conv_workspace_bytes(d) when bwd_ws != NULL (checked)              */
 } nr_conv_desc;
+size_t nr_conv_workspace_bytes(const nr_conv_desc* d);
 int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream);
 /* dw_pack [N, 3*Dp] fp32 accumulated (nr_unpack_conv_dw -> [N, D, 3]); db [N] accumulated.
  * The title-embedding table is frozen on this path (src/demo.sh:12): no dtable.             */
@@ -168,11 +205,14 @@ typedef struct {
   const float* b1;   /* [q] */
   const float* w2;   /* [q] (att_fc2.weight [1, q]) */
   const float* b2;   /* [1] */
+  size_t partial_bytes; /* nr_additive_pool_bwd: size of `partial` in bytes, >= nr_pool_workspace_bytes(d) (checked) */
 } nr_pool_desc;
+/* Bytes of the `partial` workspace of nr_additive_pool_bwd. */
+size_t nr_pool_workspace_bytes(const nr_pool_desc* d);
 /* e: [n*L, q] dtype (tanh output, saved); alpha: [n*L] fp32 (saved); out: fp32, row i at out + i*ld_out. */
 int nr_additive_pool_fwd(const nr_pool_desc* d, void* e, float* alpha, float* out, int ld_out, nr_stream_t stream);
 /* g: fp32 d(out), row i at g + i*ld_g.  w1_t [N, ldw1t] dtype = w1^T.  dpre: workspace [n*L, q] dtype.
- * partial: workspace fp32 [n * (q+1)] (one row per workgroup; small n uses one sequence per workgroup; at the news level the
+ * partial: workspace of nr_pool_workspace_bytes(d) bytes, fp32 (one row per workgroup; small n uses one sequence per workgroup; at the news level the
  *          unused tail holds the int32 flags / live-slab list of the sequences whose pooled gradient g is not all zero --
  *          sequences with g == 0 get exact zeros in dpre / dx and are skipped by the att_fc1 weight gradient).
  * dw1 [q,N], db1 [q], dw2 [q], db2 [1]: accumulated.
@@ -206,9 +246,12 @@ typedef struct {
   const float* bias; /* [N] or NULL */
   const void* w_t;   /* [K, ldwt] dtype = w^T; only read by nr_linear_bwd when dtable != NULL */
   int ldwt;
+  size_t dout_ws_bytes; /* nr_linear_bwd: size of dout_ws in bytes, >= nr_linear_workspace_bytes(d) (checked) */
 } nr_linear_desc;
+size_t nr_linear_workspace_bytes(const nr_linear_desc* d);
 int nr_linear_fwd(const nr_linear_desc* d, float* out, int ld_out, nr_stream_t stream);
-/* dout fp32 (row stride ld_dout); dout_ws: workspace [M, Nc] dtype, Nc = N rounded up to a chunk.
+/* dout fp32 (row stride ld_dout); dout_ws: workspace of nr_linear_workspace_bytes(d) bytes ([M, Nc] dtype, Nc = N rounded
+ * up to a chunk).
  * dw [N, K], db [N] accumulated; dtable [V, K] fp32 accumulated (gather source, skips id 0) or NULL. */
 int nr_linear_bwd(const nr_linear_desc* d, const float* dout, int ld_dout, void* dout_ws, float* dw,
                   float* db, float* dtable, nr_stream_t stream);
@@ -229,6 +272,46 @@ int nr_score_ce_bwd(const float* cand, int ld_cand, const float* user, const int
  * score[i] = <news_vecs[cand_ids[i]], user[imp_of[i]]>, i in [0, n_cand).                     */
 int nr_score_eval(const float* news_vecs, int ld_news, const int32_t* cand_ids, const int32_t* imp_of,
                   const float* user, int ld_user, float* score, int n_cand, int N, nr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * f1  device-side batch assembly -- DatasetTrain.line_mapper's `news_combined[...]` gathers + the positive splice +
+ * the DataLoader collate, src/dataset.py:44-49, src/main.py:89-103.  Only news INDICES come from the host (once per
+ * epoch); the feature rows are gathered here.
+ *   news_combined [n_rows, F] int32 (src/preprocess.py:50-72: title token ids, or [news, category, subcategory] ids)
+ *   hist_idx [B, H] news indices (front padded with 0, src/dataset.py:17-24); pos_idx [B]; neg_idx [B, K];
+ *   label [B] int64 = position of the positive (random.randint(0, K), src/dataset.py:45)
+ *   history [B, H, F] = news_combined[hist_idx]
+ *   candidate [B, 1+K, F]: slot j holds neg[j] for j < label, pos for j == label, neg[j-1] beyond (src/dataset.py:46)
+ * bad (optional, DEVICE int32, accumulated): number of out-of-range indices / labels met (row 0 / label 0 is used
+ * instead; numpy / torch would raise IndexError).                                                               */
+int nr_assemble_batch(const int32_t* news_combined, int n_rows, int F, const int32_t* hist_idx, const int32_t* pos_idx,
+                      const int32_t* neg_idx, const int64_t* label, int B, int H, int K, int32_t* history, int32_t* candidate,
+                      int32_t* bad, nr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * f2  on-device ranking metrics -- src/metrics.py:5-23 (dcg/ndcg/mrr), sklearn roc_auc_score (src/metrics.py:1),
+ * accumulated as src/main.py:249-263 does.  Impression i owns score / label entries [offsets[i], offsets[i+1]).
+ * Impressions whose labels are all 0 or all 1 are skipped (src/main.py:250).  Computed in fp64.
+ *   per_imp: workspace of nr_eval_metrics_workspace_bytes(n_imp) bytes; afterwards row i = [AUC, MRR, nDCG@5, nDCG@10]
+ *            of impression i (AUC = -1 marks a skipped impression)
+ *   sums[5] (fp64, overwritten) = [scored impressions, sum AUC, sum MRR, sum nDCG@5, sum nDCG@10], reduced in a
+ *            fixed order (bit-reproducible)
+ * max_cand: largest candidate count of an impression (host knowledge of `offsets`); at most 4096.
+ * Ties between scores: descending order with the LATER candidate first (np.argsort(kind="stable")[::-1]); numpy's
+ * default sort leaves the order of tied scores unspecified.                                                    */
+size_t nr_eval_metrics_workspace_bytes(int n_imp);
+int nr_eval_metrics(const float* score, const int32_t* label, const int32_t* offsets, int n_imp, int max_cand, double* per_imp,
+                    size_t per_imp_bytes, double* sums, nr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * f4  Adam (torch.optim.Adam defaults of src/main.py:76: no weight decay, no amsgrad) over ONE flat fp32 bucket:
+ *   g' = grad * grad_scale (the 1/world of the gradient all-reduce-mean, src/main.py:82 semantics)
+ *   m = lerp(m, g', 1-beta1); v = beta2 v + (1-beta2) g'^2;
+ *   param -= lr / (1-beta1^step) * m / (sqrt(v) / sqrt(1-beta2^step) + eps)
+ * zero_grad != 0: grad is cleared in the same pass (the next step's optimizer.zero_grad(), src/main.py:108).
+ * step >= 1 is the 1-based update count.  Buffers 16-byte aligned.                                               */
+int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2, float eps,
+                 int step, float grad_scale, int zero_grad, nr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Per-kernel timing (measurement only).  While enabled, every kernel launch inside the library is

@@ -27,36 +27,54 @@ class MhsaDesc(C.Structure):
                 ("dtype", C.c_int), ("src_kind", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int), ("ids", C.c_void_p),
                 ("p_in", C.c_float), ("seed_in", C.c_uint32), ("p_out", C.c_float), ("seed_out", C.c_uint32),
                 ("mask", C.c_void_p), ("w_qkv", C.c_void_p), ("ldw", C.c_int), ("b_qkv", C.c_void_p),
-                ("x_rows", C.c_void_p), ("ld_rows", C.c_int), ("row_ws", C.c_void_p), ("row_ws_ready", C.c_int)]
+                ("x_rows", C.c_void_p), ("ld_rows", C.c_int), ("row_ws", C.c_void_p), ("row_ws_bytes", C.c_size_t),
+                ("row_ws_ready", C.c_int)]
 
 
 class ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("T", C.c_int), ("D", C.c_int), ("Dp", C.c_int), ("N", C.c_int), ("dtype", C.c_int),
                 ("table", C.c_void_p), ("ids", C.c_void_p), ("ids_stride", C.c_int), ("p_in", C.c_float),
                 ("seed_in", C.c_uint32), ("w_pack", C.c_void_p), ("bias", C.c_void_p), ("x_rows", C.c_void_p),
-                ("ld_rows", C.c_int), ("bwd_ws", C.c_void_p)]
+                ("ld_rows", C.c_int), ("bwd_ws", C.c_void_p), ("bwd_ws_bytes", C.c_size_t)]
 
 
 class PoolDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("L", C.c_int), ("N", C.c_int), ("q", C.c_int), ("dtype", C.c_int), ("x", C.c_void_p),
                 ("mask", C.c_void_p), ("w1", C.c_void_p), ("ldw1", C.c_int), ("b1", C.c_void_p), ("w2", C.c_void_p),
-                ("b2", C.c_void_p)]
+                ("b2", C.c_void_p), ("partial_bytes", C.c_size_t)]
 
 
 class LinearDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("K", C.c_int), ("N", C.c_int), ("dtype", C.c_int), ("src_kind", C.c_int),
                 ("x", C.c_void_p), ("ldx", C.c_int), ("ids", C.c_void_p), ("ids_stride", C.c_int), ("w", C.c_void_p),
-                ("ldw", C.c_int), ("bias", C.c_void_p), ("w_t", C.c_void_p), ("ldwt", C.c_int)]
+                ("ldw", C.c_int), ("bias", C.c_void_p), ("w_t", C.c_void_p), ("ldwt", C.c_int), ("dout_ws_bytes", C.c_size_t)]
 
 
 _vp, _i, _f, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_uint32
-# name -> argtypes ; every entry returns int.  Must list exactly the symbols of include/nrhip.h.
+# name -> argtypes ; every entry returns int unless listed in RESTYPES.  Must list exactly the symbols of include/nrhip.h.
+RESTYPES = {"nr_eval_metrics_workspace_bytes": C.c_size_t, "nr_mhsa_workspace_bytes": C.c_size_t, "nr_conv_workspace_bytes": C.c_size_t, "nr_pool_workspace_bytes": C.c_size_t,
+            "nr_linear_workspace_bytes": C.c_size_t}
 SIGNATURES = {
     "nr_version": [],
     "nr_last_error": [C.c_char_p, C.c_size_t],
+    "nr_abi_sizes": [C.POINTER(C.c_size_t), _i],
+    "nr_set_option": [C.c_char_p, _i],
+    "nr_get_option": [C.c_char_p],
+    "nr_mhsa_workspace_bytes": [C.POINTER(MhsaDesc)],
+    "nr_conv_workspace_bytes": [C.POINTER(ConvDesc)],
+    "nr_pool_workspace_bytes": [C.POINTER(PoolDesc)],
+    "nr_linear_workspace_bytes": [C.POINTER(LinearDesc)],
+    "nr_sdpa_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u32, _vp],
+    "nr_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u32, _vp],
+    "nr_assemble_batch": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "nr_eval_metrics_workspace_bytes": [_i],
+    "nr_eval_metrics": [_vp, _vp, _vp, _i, _i, _vp, C.c_size_t, _vp, _vp],
+    "nr_adam_step": [_vp, _vp, _vp, _vp, C.c_size_t, _f, _f, _f, _f, _i, _f, _i, _vp],
+    "nr_check_ids": [_vp, _i, _i, _i, _vp, _vp],
+    "nr_check_labels": [_vp, _i, _i, _vp, _vp],
     "nr_cast_pad": [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp],
     "nr_pack_conv_w": [_vp, _i, _i, _vp, _i, _i, _vp],
-    "nr_unpack_conv_dw": [_vp, _i, _i, _i, _vp, _vp],
+    "nr_unpack_conv_dw": [_vp, _i, _i, _i, _vp, _i, _vp],
     "nr_embed_gather_fwd": [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp],
     "nr_embed_gather_bwd": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp],
     "nr_mhsa_fwd_fused": [C.POINTER(MhsaDesc)],
@@ -118,7 +136,11 @@ def lib():
                 for name, argtypes in SIGNATURES.items():
                     fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
                     fn.argtypes = argtypes
-                    fn.restype = C.c_int
+                    fn.restype = RESTYPES.get(name, C.c_int)
+                sizes = (C.c_size_t * 4)()
+                if L.nr_abi_sizes(sizes, 4) != 0 or list(sizes) != [C.sizeof(t) for t in (MhsaDesc, ConvDesc, PoolDesc, LinearDesc)]:
+                    raise RuntimeError(f"libnrhip.so descriptor layout {list(sizes)} differs from the ctypes binding "
+                                       f"{[C.sizeof(t) for t in (MhsaDesc, ConvDesc, PoolDesc, LinearDesc)]}: rebuild the library")
                 _lib = L
     return _lib
 
@@ -132,6 +154,15 @@ def last_error() -> str:
 def check(rc: int, what: str) -> None:
     if rc != 0:
         raise RuntimeError(f"libnrhip {what} failed (code {rc}): {last_error()}")
+
+
+def set_option(name: str, value: int) -> None:
+    """Library switch (csrc/nr_common.h NrOpt), e.g. set_option("NO_SLABS", 1)."""
+    check(lib().nr_set_option(name.encode(), int(value)), "nr_set_option")
+
+
+def get_option(name: str) -> int:
+    return int(lib().nr_get_option(name.encode()))
 
 
 def prof_enable(on) -> None:

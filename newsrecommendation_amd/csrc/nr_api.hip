@@ -30,6 +30,33 @@ int nr_launch_mhsa_fused_fwd(const void* table, int ldt, const int32_t* ids, con
 
 static thread_local char g_err[512] = "";
 
+// ---- library options (nr_common.h: NrOpt) ------------------------------------------------------
+#include <atomic>
+namespace {
+struct OptDef { const char* name; int def; };
+const OptDef g_opt_defs[NR_OPT_COUNT] = {
+    {"NO_SLABS", 0},   {"NO_ATTN_SKIP", 0}, {"SIDE_STREAM", 0}, {"ATTN_OLD", 0},  {"ATTN_VALU", 0},   {"NO_PAD_SUB", 0},
+    {"NO_FUSED_FWD", 0}, {"NO_TN3", 0},     {"TN_V1", 0},       {"TN3_ROUNDS", 0}, {"TN3_WK", 0},      {"TN3_NI", 0},
+    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}};
+std::atomic<int> g_opt[NR_OPT_COUNT];
+std::once_flag g_opt_once;
+void opt_init() {
+  for (int i = 0; i < NR_OPT_COUNT; ++i) {
+    int v = g_opt_defs[i].def;
+    char env[64];
+    snprintf(env, sizeof(env), "NR_%s", g_opt_defs[i].name);
+    const char* e = getenv(env);               // the ONLY environment lookup of the library, once per process
+    if (e != nullptr) v = (e[0] >= '0' && e[0] <= '9') || e[0] == '-' ? atoi(e) : 1;
+    g_opt[i].store(v, std::memory_order_relaxed);
+  }
+}
+}  // namespace
+int nr_opt(int which) {
+  std::call_once(g_opt_once, opt_init);
+  return (which >= 0 && which < NR_OPT_COUNT) ? g_opt[which].load(std::memory_order_relaxed) : 0;
+}
+
+
 // ---- per-kernel timing ---------------------------------------------------------------------
 bool g_nr_prof_on = false;
 namespace {
@@ -106,8 +133,7 @@ thread_local SideStream g_side;
 // Opt-in (NR_SIDE_STREAM=1): measured 9.66 -> 9.43 ms/step at the bench shape; off by default because overlapped
 // launches no longer have a per-kernel duration of their own, which the roofline accounting of bench.py relies on.
 bool side_enabled() {
-  static const bool on = [] { const char* e = getenv("NR_SIDE_STREAM"); return e != nullptr && e[0] == '1'; }();
-  return on;
+  return nr_opt(NR_OPT_SIDE_STREAM) != 0;
 }
 int side_fork(hipStream_t main, hipStream_t* out) {
   int dev = 0;
@@ -161,6 +187,28 @@ static int mhsa_rows(const nr_mhsa_desc* d, RowSrc* out) {
   return NR_OK;
 }
 
+// ---- workspace layouts: the ONE place the formulas live (exported as nr_*_workspace_bytes) --------------------
+// row_ws (int32): [0,4) counters | M live rows | M their ids | M padding rows | n per-sequence live-token masks |
+//                 slab scratch: n title flags, 4 counters, M/32 slab ids, 4 pad | sequence list: 4 counters, n entries
+struct MhsaWs {
+  size_t live_idx, live_ids, dead_idx, tmask, slab, seq, total;   // offsets in int32 elements
+};
+static MhsaWs mhsa_ws_layout(int n, int L) {
+  const size_t M = (size_t)n * L;
+  MhsaWs w;
+  w.live_idx = 4; w.live_ids = 4 + M; w.dead_idx = 4 + 2 * M; w.tmask = 4 + 3 * M;
+  w.slab = w.tmask + n;
+  w.seq = w.slab + n + 4 + M / 32 + 4;
+  w.total = w.seq + 4 + n + 4;
+  return w;
+}
+// bwd_ws of the convolution (int32): n title flags | 4 counters | M/32 slab ids | pad
+static size_t conv_ws_elems(int n, int T) { return (size_t)n + 4 + ((size_t)n * T) / 32 + 12; }
+int nr_pool_partial_rows(int n);
+// `partial` of the pooling backward (fp32): nr_pool_partial_rows(n) rows of (q+1) | int32 scratch: n flags, 4 counters, M/32 slabs
+static size_t pool_ws_used(int n, int q) { return ((size_t)nr_pool_partial_rows(n) * (q + 1) + 3) / 4 * 4; }
+static size_t pool_ws_elems(int n, int L, int q) { return pool_ws_used(n, q) + (size_t)n + 8 + ((size_t)n * L) / 32 + 4; }
+
 static int mhsa_check(const nr_mhsa_desc* d) {
   NR_CHECK_ARG(d != nullptr, "mhsa: null descriptor");
   NR_CHECK_ARG(dtype_ok(d->dtype), "mhsa: bad dtype %d", d->dtype);
@@ -174,12 +222,15 @@ static int mhsa_check(const nr_mhsa_desc* d) {
   NR_CHECK_ARG(d->n == 0 || (d->x && d->w_qkv && d->b_qkv), "mhsa: null operand");
   NR_CHECK_ARG(d->p_in >= 0.f && d->p_in < 1.f && d->p_out >= 0.f && d->p_out < 1.f, "mhsa: dropout p out of range");
   NR_CHECK_ARG((uint64_t)d->n * d->L * (uint64_t)(3 * d->heads * d->d_head) < 0xffffffffull, "mhsa: problem too large for 32-bit element counters");
+  NR_CHECK_ARG(d->row_ws == nullptr || d->row_ws_bytes >= mhsa_ws_layout(d->n, d->L).total * sizeof(int32_t),
+               "mhsa: row_ws holds %zu bytes, nr_mhsa_workspace_bytes() asks for %zu", d->row_ws_bytes,
+               mhsa_ws_layout(d->n, d->L).total * sizeof(int32_t));
   return NR_OK;
 }
 
 extern "C" {
 
-int nr_version(void) { return 101; }
+int nr_version(void) { return 200; }
 
 int nr_prof_enable(int on) {
   g_nr_prof_on = on != 0;
@@ -225,9 +276,125 @@ int nr_last_error(char* buf, size_t n) {
   return (int)strlen(g_err);
 }
 
+int nr_abi_sizes(size_t* out, int n) {
+  NR_CHECK_ARG(out != nullptr && n >= 4, "abi_sizes: need room for 4 entries");
+  out[0] = sizeof(nr_mhsa_desc); out[1] = sizeof(nr_conv_desc); out[2] = sizeof(nr_pool_desc); out[3] = sizeof(nr_linear_desc);
+  return NR_OK;
+}
+
+int nr_set_option(const char* name, int value) {
+  NR_CHECK_ARG(name != nullptr, "set_option: null name");
+  (void)nr_opt(0);                                 // environment presets first, so that this call wins
+  if (strncmp(name, "NR_", 3) == 0) name += 3;
+  for (int i = 0; i < NR_OPT_COUNT; ++i)
+    if (strcmp(name, g_opt_defs[i].name) == 0) {
+      g_opt[i].store(value, std::memory_order_relaxed);
+      return NR_OK;
+    }
+  nr_set_error("set_option: unknown option %s", name);
+  return NR_ERR_ARG;
+}
+
+int nr_get_option(const char* name) {
+  if (name == nullptr) return -1;
+  if (strncmp(name, "NR_", 3) == 0) name += 3;
+  for (int i = 0; i < NR_OPT_COUNT; ++i)
+    if (strcmp(name, g_opt_defs[i].name) == 0) return nr_opt(i);
+  return -1;
+}
+
+size_t nr_mhsa_workspace_bytes(const nr_mhsa_desc* d) {
+  return (d == nullptr || d->n < 0 || d->L < 1) ? 0 : mhsa_ws_layout(d->n, d->L).total * sizeof(int32_t);
+}
+size_t nr_conv_workspace_bytes(const nr_conv_desc* d) {
+  return (d == nullptr || d->n < 0 || d->T < 1) ? 0 : conv_ws_elems(d->n, d->T) * sizeof(int32_t);
+}
+size_t nr_pool_workspace_bytes(const nr_pool_desc* d) {
+  return (d == nullptr || d->n < 0 || d->L < 1 || d->q < 1) ? 0 : pool_ws_elems(d->n, d->L, d->q) * sizeof(float);
+}
+size_t nr_linear_workspace_bytes(const nr_linear_desc* d) {
+  if (d == nullptr || d->M < 0 || d->N < 1 || !dtype_ok(d->dtype)) return 0;
+  return (size_t)d->M * round_up(d->N, nr_chunk(d->dtype)) * nr_elt_size(d->dtype);
+}
+
+// ---------------------------------------------------------------------------------------- index validation
+namespace {
+__global__ __launch_bounds__(256) void check_ids_kernel(const int32_t* __restrict__ ids, int count, int stride, int rows,
+                                                        int32_t* __restrict__ bad) {
+  int nbad = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+    const int v = ids[i * stride];
+    nbad += (v < 0 || v >= rows) ? 1 : 0;
+  }
+  nbad = (int)wave_sum((float)nbad);
+  if ((threadIdx.x & 63) == 0 && nbad) atomicAdd(bad, nbad);
+}
+__global__ __launch_bounds__(256) void check_labels_kernel(const int64_t* __restrict__ label, int count, int classes,
+                                                           int32_t* __restrict__ bad) {
+  int nbad = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+    const int64_t v = label[i];
+    nbad += (v < 0 || v >= classes) ? 1 : 0;
+  }
+  nbad = (int)wave_sum((float)nbad);
+  if ((threadIdx.x & 63) == 0 && nbad) atomicAdd(bad, nbad);
+}
+}  // namespace
+
+int nr_check_ids(const int32_t* ids, int count, int stride, int rows, int32_t* bad, nr_stream_t stream) {
+  NR_CHECK_ARG(count >= 0 && stride >= 1 && rows >= 0 && bad != nullptr && (count == 0 || ids != nullptr), "check_ids: bad arguments");
+  if (count == 0) return NR_OK;
+  NR_DEVICE_GUARD(stream, bad);
+  const int blocks = count / 256 + 1 > 1024 ? 1024 : count / 256 + 1;
+  hipLaunchKernelGGL(check_ids_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ids, count, stride, rows, bad);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_check_labels(const int64_t* label, int count, int classes, int32_t* bad, nr_stream_t stream) {
+  NR_CHECK_ARG(count >= 0 && classes >= 0 && bad != nullptr && (count == 0 || label != nullptr), "check_labels: bad arguments");
+  if (count == 0) return NR_OK;
+  NR_DEVICE_GUARD(stream, bad);
+  const int blocks = count / 256 + 1 > 1024 ? 1024 : count / 256 + 1;
+  hipLaunchKernelGGL(check_labels_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, label, count, classes, bad);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+// ---------------------------------------------------------------------------------------- attention core alone
+static int sdpa_check(const void* qkv, int n, int L, int heads, int d_head, int dtype, float p_out) {
+  NR_CHECK_ARG(dtype_ok(dtype), "sdpa: bad dtype %d", dtype);
+  NR_CHECK_ARG(n >= 0 && L >= 1 && L <= 64 && heads >= 1 && d_head >= 1, "sdpa: bad shape n=%d L=%d heads=%d d_head=%d", n, L, heads, d_head);
+  NR_CHECK_ARG(n == 0 || qkv != nullptr, "sdpa: null operand");
+  NR_CHECK_ARG(p_out >= 0.f && p_out < 1.f, "sdpa: dropout p out of range");
+  NR_CHECK_ARG((uint64_t)n * L * (uint64_t)(3 * heads * d_head) < 0xffffffffull, "sdpa: problem too large for 32-bit element counters");
+  return NR_OK;
+}
+
+int nr_sdpa_fwd(const void* qkv, const float* mask, void* y, int n, int L, int heads, int d_head, int dtype, float p_out,
+                uint32_t seed_out, nr_stream_t stream) {
+  int rc = sdpa_check(qkv, n, L, heads, d_head, dtype, p_out);
+  if (rc) return rc;
+  if (n == 0) return NR_OK;
+  NR_CHECK_ARG(y != nullptr, "sdpa_fwd: null output");
+  NR_DEVICE_GUARD(stream, y);
+  return nr_launch_attn(false, dtype, qkv, mask, y, nullptr, nullptr, n, L, heads, d_head, nr_make_drop(p_out, seed_out), (hipStream_t)stream);
+}
+
+int nr_sdpa_bwd(const void* qkv, const float* mask, const void* dy, void* dqkv, int n, int L, int heads, int d_head, int dtype,
+                float p_out, uint32_t seed_out, nr_stream_t stream) {
+  int rc = sdpa_check(qkv, n, L, heads, d_head, dtype, p_out);
+  if (rc) return rc;
+  if (n == 0) return NR_OK;
+  NR_CHECK_ARG(dy != nullptr && dqkv != nullptr, "sdpa_bwd: null operand");
+  NR_DEVICE_GUARD(stream, dqkv);
+  return nr_launch_attn(true, dtype, qkv, mask, nullptr, dy, dqkv, n, L, heads, d_head, nr_make_drop(p_out, seed_out), (hipStream_t)stream);
+}
+
 int nr_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, const float* bias, int act_tanh, void* C, int ldc,
                int out_dtype, int M, int N, int K, nr_stream_t stream) {
   NR_CHECK_ARG(dtype_ok(dtype) && dtype_ok(out_dtype) && A && B && C, "gemm_nt: bad dtype / null operand");
+  NR_DEVICE_GUARD(stream, C);
   RowSrc a = dense_rows(A, lda, K);
   EpiArgs ep = store_epi(C, ldc, out_dtype, bias, act_tanh);
   return nr_launch_gemm_nt(dtype, a, B, ldb, M, N, K, EPI_STORE, ep, (hipStream_t)stream);
@@ -236,6 +403,7 @@ int nr_gemm_nt(int dtype, const void* A, int lda, const void* B, int ldb, const 
 int nr_gemm_tn(int dtype, const void* dC, int ldc, const void* A, int lda, float* dW, int ldw, float* db, int M, int N, int K,
                nr_stream_t stream) {
   NR_CHECK_ARG(dtype_ok(dtype) && dC && A && dW, "gemm_tn: bad dtype / null operand");
+  NR_DEVICE_GUARD(stream, dW);
   RowSrc a = dense_rows(A, lda, K);
   return nr_launch_gemm_tn(dtype, dC, ldc, a, dW, ldw, db, M, N, K, N, K, (hipStream_t)stream);
 }
@@ -255,7 +423,9 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   if (d->n == 0) return NR_OK;
   NR_CHECK_ARG(y != nullptr, "mhsa_fwd: null output");
   hipStream_t s = (hipStream_t)stream;
+  NR_DEVICE_GUARD(stream, y);
   const int N = d->heads * d->d_head, M = d->n * d->L, Kp = round_up(d->d_model, nr_chunk(d->dtype));
+  const MhsaWs W = mhsa_ws_layout(d->n, d->L);
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
   if (qkv == nullptr && d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER) {
@@ -280,13 +450,13 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
       // only (compacted on the device) and write the bias into the others.  If table row 0 is not zero, the
       // compaction keeps every row and nothing changes.
       if ((rc = nr_launch_compact_rows_fwd(d->ids, M, d->n, d->L, d->x, d->d_model, d->row_ws, s))) return rc;
-      ep.row_count = d->row_ws; ep.row_idx = d->row_ws + 4; ep.row_ids = d->row_ws + 4 + M;
+      ep.row_count = d->row_ws; ep.row_idx = d->row_ws + W.live_idx; ep.row_ids = d->row_ws + W.live_ids;
       // Sequences made of padding tokens only (empty history slots, ~45 % of the titles of a MIND-shaped batch): the
       // attention kernels take their Q|K|V from the bias themselves (per-sequence live mask == 0), so those qkv rows are
       // neither written here nor read there.  The bias goes into the padding rows of the other sequences.
       if (d->b_qkv != nullptr && nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, y))
-        tmask = reinterpret_cast<const uint32_t*>(d->row_ws + 4 + 3 * (size_t)M);
-      if ((rc = nr_launch_bias_rows(qkv, 3 * N, 3 * N, d->b_qkv, d->row_ws + 4 + 2 * (size_t)M, d->row_ws + 1, M, tmask, d->L, s)))
+        tmask = reinterpret_cast<const uint32_t*>(d->row_ws + W.tmask);
+      if ((rc = nr_launch_bias_rows(qkv, 3 * N, 3 * N, d->b_qkv, d->row_ws + W.dead_idx, d->row_ws + 1, M, tmask, d->L, s)))
         return rc;
     }
   }
@@ -302,7 +472,9 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
   if (d->n == 0) return NR_OK;
   NR_CHECK_ARG(qkv && dy && dqkv && dw_qkv && db_qkv, "mhsa_bwd: null operand");
   hipStream_t s = (hipStream_t)stream;
+  NR_DEVICE_GUARD(stream, dqkv);
   const int N = d->heads * d->d_head, M = d->n * d->L, ch = nr_chunk(d->dtype), Kp = round_up(d->d_model, ch);
+  const MhsaWs W = mhsa_ws_layout(d->n, d->L);
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
   // row_ws_ready: the forward compacted the rows and (when the attention kernels support it) left the qkv rows of
@@ -313,24 +485,24 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
     // shape-wise the forward substituted; whether it really did also hung on the alignment of its qkv / y
     NR_CHECK_ARG(nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, dqkv) && (((uintptr_t)dy) & 7) == 0,
                  "mhsa_bwd: the forward left padding rows of qkv unwritten; qkv / dy / dqkv must be 8-byte aligned");
-    tmask = reinterpret_cast<const uint32_t*>(d->row_ws + 4 + 3 * (size_t)M);
+    tmask = reinterpret_cast<const uint32_t*>(d->row_ws + W.tmask);
   }
   // Sequences whose upstream gradient dy is exactly zero (history slots the user encoder masks out) get exact zeros in
   // dQ|dK|dV (dP = dy.V^T = 0, so dS = 0): a pass over dy flags the others, and the weight-gradient GEMM contracts only
   // the 32-row slabs that touch a flagged sequence.  Scratch: the tail of row_ws (n flags, count, M/32 slab ids).
-  static const bool no_slabs = getenv("NR_NO_SLABS") != nullptr;
+  const bool no_slabs = nr_opt(NR_OPT_NO_SLABS) != 0;
   int32_t* slab_ws = nullptr;
   int32_t* seq_ws = nullptr;
   if (!no_slabs && d->row_ws != nullptr && d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER && d->x_rows != nullptr && M % 32 == 0 &&
       M >= 4096 && nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, dqkv) && (((uintptr_t)dy) & 7) == 0 &&
       nr_gemm_tn_slabs_ok(3 * N, d->ld_rows, M, 3 * N, Kp)) {
-    slab_ws = d->row_ws + 4 + 3 * (size_t)M + d->n;
+    slab_ws = d->row_ws + W.slab;
     if ((rc = nr_launch_title_flags(dy, d->n, d->L, N, slab_ws, s))) return rc;    // one pass over dy (bf16 [M, N])
     if ((rc = nr_launch_live_slabs(slab_ws, d->n, d->L, s))) return rc;
-    static const bool no_skip = getenv("NR_NO_ATTN_SKIP") != nullptr;
+    const bool no_skip = nr_opt(NR_OPT_NO_ATTN_SKIP) != 0;
     if (tmask != nullptr && !no_skip) {
       // the attention backward walks a list that leaves out the all-padding sequences no live slab comes near
-      seq_ws = slab_ws + d->n + 4 + M / 32 + 4;
+      seq_ws = d->row_ws + W.seq;
       if ((rc = nr_launch_seq_list(slab_ws, tmask, d->n, d->L, seq_ws, s))) return rc;
     }
   }
@@ -367,7 +539,7 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
       if (d->row_ws != nullptr && d->dtype == NR_BF16 && M >= 4096) {
         // only rows with a non-padding token id reach the table gradient: compact them, GEMM over those alone
         if (!d->row_ws_ready && (rc = nr_launch_compact_rows(d->ids, 1, M, d->row_ws, s))) return rc;
-        ep.row_count = d->row_ws; ep.row_idx = d->row_ws + 4; ep.row_ids = d->row_ws + 4 + M;
+        ep.row_count = d->row_ws; ep.row_idx = d->row_ws + W.live_idx; ep.row_ids = d->row_ws + W.live_ids;
       }
       rc = nr_launch_gemm_nt(d->dtype, G, w_qkv_t, ldwt, M, d->d_model, 3 * N, EPI_SCATTER, ep, s);
     } else {
@@ -409,6 +581,7 @@ int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream) {
   if (rc) return rc;
   if (d->n == 0) return NR_OK;
   NR_CHECK_ARG(y != nullptr, "conv1d_fwd: null output");
+  NR_DEVICE_GUARD(stream, y);
   EpiArgs ep = store_epi(y, d->N, d->dtype, d->bias, 0);
   hipStream_t s = (hipStream_t)stream;
   const int M = d->n * d->T, K = 3 * d->Dp;
@@ -427,11 +600,15 @@ int nr_conv1d_k3_bwd(const nr_conv_desc* d, const void* dy, float* dw_pack, floa
   if (rc) return rc;
   if (d->n == 0) return NR_OK;
   NR_CHECK_ARG(dy && dw_pack && db, "conv1d_bwd: null operand");
+  NR_DEVICE_GUARD(stream, dw_pack);
+  NR_CHECK_ARG(d->bwd_ws == nullptr || d->bwd_ws_bytes >= conv_ws_elems(d->n, d->T) * sizeof(int32_t),
+               "conv1d_bwd: bwd_ws holds %zu bytes, nr_conv_workspace_bytes() asks for %zu", d->bwd_ws_bytes,
+               conv_ws_elems(d->n, d->T) * sizeof(int32_t));
   if (d->x_rows != nullptr) {   // the rows the forward stored
     NR_CHECK_ARG(d->ld_rows >= 3 * d->Dp, "conv1d_bwd: ld_rows=%d must cover %d", d->ld_rows, 3 * d->Dp);
     A = dense_rows(d->x_rows, d->ld_rows, 3 * d->Dp);
     // titles with an exactly zero upstream gradient (masked history slots) add nothing to dW / db: live slabs only
-    static const bool no_slabs = getenv("NR_NO_SLABS") != nullptr;
+    const bool no_slabs = nr_opt(NR_OPT_NO_SLABS) != 0;
     const int M = d->n * d->T;
     if (!no_slabs && d->bwd_ws != nullptr && d->dtype == NR_BF16 && M % 32 == 0 && d->T <= 32 && d->N % 8 == 0 &&
         (((uintptr_t)dy) & 15) == 0 && nr_gemm_tn_slabs_ok(d->N, d->ld_rows, M, d->N, 3 * d->Dp)) {
@@ -464,6 +641,7 @@ int nr_additive_pool_fwd(const nr_pool_desc* d, void* e, float* alpha, float* ou
   if (rc) return rc;
   if (d->n == 0) return NR_OK;
   NR_CHECK_ARG(e && alpha && out && ld_out >= d->N, "additive_pool_fwd: null output / ld_out");
+  NR_DEVICE_GUARD(stream, out);
   hipStream_t s = (hipStream_t)stream;
   RowSrc A = dense_rows(d->x, d->N, d->N);
   EpiArgs ep = store_epi(e, d->q, d->dtype, d->b1, 1);
@@ -478,18 +656,20 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
   if (rc) return rc;
   if (d->n == 0) return NR_OK;
   NR_CHECK_ARG(e && alpha && g && dpre && partial && dw1 && db1 && dw2 && db2, "additive_pool_bwd: null operand");
+  NR_DEVICE_GUARD(stream, dpre);
+  NR_CHECK_ARG(d->partial_bytes >= pool_ws_elems(d->n, d->L, d->q) * sizeof(float),
+               "additive_pool_bwd: partial holds %zu bytes, nr_pool_workspace_bytes() asks for %zu", d->partial_bytes,
+               pool_ws_elems(d->n, d->L, d->q) * sizeof(float));
   hipStream_t s = (hipStream_t)stream;
   const int M = d->n * d->L;
   // A sequence whose pooled gradient g is exactly zero (a history slot the user encoder masks out) has dA = <g, x> = 0,
   // so ds = 0 and its dpre rows are exact zeros: the core kernel only writes those zeros for it, and the att_fc1 weight
   // gradient contracts only the 32-row slabs that touch a sequence with g != 0.  The int scratch (n flags, count, M/32
   // slab ids) lives in the unused tail of `partial` (its first nr_pool_partial_rows(n) rows are taken).
-  static const bool no_slabs = getenv("NR_NO_SLABS") != nullptr;
-  const size_t used = (size_t)nr_pool_partial_rows(d->n) * (d->q + 1), need = (size_t)d->n + 8 + M / 32;
+  const bool no_slabs = nr_opt(NR_OPT_NO_SLABS) != 0;
   int32_t* ws = nullptr;
-  if (!no_slabs && d->dtype == NR_BF16 && M % 32 == 0 && d->L <= 32 && nr_gemm_tn_slabs_ok(d->q, d->N, M, d->q, d->N) &&
-      used + need + 4 <= (size_t)d->n * (d->q + 1)) {
-    ws = reinterpret_cast<int32_t*>(partial + ((used + 3) / 4) * 4);
+  if (!no_slabs && d->dtype == NR_BF16 && M % 32 == 0 && d->L <= 32 && nr_gemm_tn_slabs_ok(d->q, d->N, M, d->q, d->N)) {
+    ws = reinterpret_cast<int32_t*>(partial + pool_ws_used(d->n, d->q));   // the int scratch behind the partial rows
     if ((rc = nr_launch_row_flags_f32(g, ld_g, d->N, d->n, ws, s))) return rc;
   }
   if ((rc = nr_launch_pool_core_bwd(d->dtype, d->x, e, d->w2, alpha, g, ld_g, dpre, partial, dw2, db2, d->n, d->L, d->N, d->q, s, ws)))
@@ -546,6 +726,7 @@ int nr_linear_fwd(const nr_linear_desc* d, float* out, int ld_out, nr_stream_t s
   if (rc) return rc;
   if (d->M == 0) return NR_OK;
   NR_CHECK_ARG(out != nullptr && ld_out >= d->N, "linear_fwd: null output / ld_out");
+  NR_DEVICE_GUARD(stream, out);
   EpiArgs ep = store_epi(out, ld_out, NR_F32, d->bias, 0);
   return nr_launch_gemm_nt(d->dtype, A, d->w, d->ldw, d->M, d->N, round_up(d->K, nr_chunk(d->dtype)), EPI_STORE, ep, (hipStream_t)stream);
 }
@@ -557,6 +738,9 @@ int nr_linear_bwd(const nr_linear_desc* d, const float* dout, int ld_dout, void*
   if (rc) return rc;
   if (d->M == 0) return NR_OK;
   NR_CHECK_ARG(dout && dout_ws && dw && db, "linear_bwd: null operand");
+  NR_DEVICE_GUARD(stream, dw);
+  NR_CHECK_ARG(d->dout_ws_bytes >= nr_linear_workspace_bytes(d), "linear_bwd: dout_ws holds %zu bytes, nr_linear_workspace_bytes() asks for %zu",
+               d->dout_ws_bytes, nr_linear_workspace_bytes(d));
   hipStream_t s = (hipStream_t)stream;
   const int ch = nr_chunk(d->dtype), Nc = round_up(d->N, ch), Kp = round_up(d->K, ch);
   if ((rc = nr_launch_cast_rows(d->dtype, dout, ld_dout, dout_ws, Nc, d->M, d->N, s))) return rc;

@@ -249,7 +249,7 @@ int nr_launch_attn(bool bwd, int dtype, const void* qkv, const float* mask, void
   NR_CHECK_ARG(L >= 1 && L <= 64, "attention: L=%d must be in [1, 64]", L);
   NR_CHECK_ARG(n >= 1 && heads >= 1, "attention: empty problem");
   // L <= 32: one wave per (sequence, head) on the matrix cores; longer sequences: LDS/VALU kernels below.
-  static const bool force_valu = getenv("NR_ATTN_VALU") != nullptr;
+  const bool force_valu = nr_opt(NR_OPT_ATTN_VALU) != 0;
   if (!force_valu && nr_attn_mfma_supported(L, d_head)) {
     const int rc = nr_launch_attn_mfma(bwd, dtype, qkv, mask, y, dy, dqkv, n, L, heads, d_head, drop, stream, tmask, bias, seq_list,
                                        seq_count);

@@ -1387,8 +1387,7 @@ bool nr_attn_mfma_supported(int L, int d_head) { return L >= 1 && L <= 64 && d_h
 // Padding-token substitution (tmask / bias) exists on the bf16 panel kernels only: L <= 32, d_head % 4 == 0, 8-byte
 // aligned tensors.  nr_attn_pad_ok tells the caller beforehand; a launch that asks for it elsewhere is an error.
 bool nr_attn_pad_ok(int dtype, int L, int d_head, const void* p0, const void* p1) {
-  static const bool old_path = getenv("NR_ATTN_OLD") != nullptr || getenv("NR_ATTN_VALU") != nullptr ||
-                               getenv("NR_NO_PAD_SUB") != nullptr;
+  const bool old_path = nr_opt(NR_OPT_ATTN_OLD) || nr_opt(NR_OPT_ATTN_VALU) || nr_opt(NR_OPT_NO_PAD_SUB);
   return !old_path && dtype == NR_BF16 && L >= 1 && L <= 32 && d_head >= 4 && d_head <= 32 && d_head % 4 == 0 &&
          (((uintptr_t)p0 | (uintptr_t)p1) & 7) == 0;
 }
@@ -1405,7 +1404,7 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   a.drop = drop;
   const uintptr_t al = dtype == NR_BF16 ? 7 : 15;
   a.vec = (d_head % 4 == 0) && (((uintptr_t)qkv | (uintptr_t)y | (uintptr_t)dy | (uintptr_t)dqkv) & al) == 0;
-  static const bool old_path = getenv("NR_ATTN_OLD") != nullptr;
+  const bool old_path = nr_opt(NR_OPT_ATTN_OLD) != 0;
   const bool fast = dtype == NR_BF16 && a.vec && !old_path;
   if (L > 32 && !fast) return -1;   // caller falls back to the LDS/VALU kernels
   // "_live": the backward walks a device-side list of sequences (n is then an upper bound)
@@ -1427,7 +1426,7 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
 // Fused title-level forward (gather + dropout + Q|K|V projection + attention + dropout), bf16 only.
 // Returns -1 when the shape is outside what the fused kernel covers (the caller then runs the unfused path).
 bool nr_mhsa_fused_shape_ok(int L, int heads, int d_head, int d_model, int ldt, int ldw) {
-  static const bool off = getenv("NR_NO_FUSED_FWD") != nullptr;
+  const bool off = nr_opt(NR_OPT_NO_FUSED_FWD) != 0;
   if (off) return false;
   return L >= 1 && L <= 32 && d_head % 4 == 0 && 3 * d_head <= 64 && d_model <= 320 && d_model > 288 && ldt >= 320 && ldw >= 320 &&
          (heads * d_head) % 4 == 0;

@@ -34,6 +34,64 @@ void nr_set_error(const char* fmt, ...);
   } while (0)
 #define NR_CHECK_LAUNCH() NR_CHECK_HIP(hipGetLastError())
 
+// ---- device guard -------------------------------------------------------------------------------
+// Every compute entry point runs on the device that owns `stream` (or, for the NULL stream, the device that owns the
+// given pointer): forward is called from the rank's main thread, backward from the autograd engine thread, and
+// hipFuncSetAttribute / hipEventCreate / kernel launches act on the calling thread's CURRENT device.  The guard
+// switches to the right device for the duration of the call and restores the previous one.
+struct DeviceGuard {
+  int prev = -1, want = -1;
+  int rc = NR_OK;
+  DeviceGuard(hipStream_t s, const void* p) {
+    if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+    if (s != nullptr) {
+      hipDevice_t d;
+      if (hipStreamGetDevice(s, &d) == hipSuccess) want = (int)d;
+    } else if (p != nullptr) {
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, p) == hipSuccess) want = at.device;
+      else (void)hipGetLastError();              // not a device pointer the runtime knows: leave the device alone
+    }
+    if (want >= 0 && want != prev) {
+      if (hipSetDevice(want) != hipSuccess) { nr_set_error("cannot switch to device %d", want); rc = NR_ERR_HIP; }
+    } else {
+      prev = -1;                                 // nothing to restore
+    }
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define NR_DEVICE_GUARD(stream, p)              \
+  DeviceGuard nr_guard__((hipStream_t)(stream), (p)); \
+  if (nr_guard__.rc) return nr_guard__.rc
+
+// ---- library options (host) -----------------------------------------------------------------
+// One table of integer switches instead of getenv() calls scattered over the launchers.  Defaults are the
+// production configuration; each entry can be preset from the environment variable NR_<NAME> (read ONCE, when the
+// first option is looked up) or changed at run time through nr_set_option() (include/nrhip.h) -- the tests use the
+// latter to compare a path with its own switched-off variant inside one process.
+enum NrOpt {
+  NR_OPT_NO_SLABS = 0,   // 1: weight-gradient GEMMs contract every row (no live-slab lists)
+  NR_OPT_NO_ATTN_SKIP,   // 1: the attention backward walks every sequence (no device-side sequence list)
+  NR_OPT_SIDE_STREAM,    // 1: weight- and input-gradient GEMMs of one backward run on two streams
+  NR_OPT_ATTN_OLD,       // 1: per-wave staging attention kernels instead of the bf16 panel kernels
+  NR_OPT_ATTN_VALU,      // 1: LDS/VALU attention kernels
+  NR_OPT_NO_PAD_SUB,     // 1: no bias substitution for all-padding sequences
+  NR_OPT_NO_FUSED_FWD,   // 1: never use the fused title-level forward kernels
+  NR_OPT_NO_TN3,         // 1: weight gradients through tn2 / v1 kernels
+  NR_OPT_TN_V1,          // 1: first-generation TN kernel
+  NR_OPT_TN3_ROUNDS,     // >0: force the number of row-split rounds of tn3
+  NR_OPT_TN3_WK,         // 2 / 4: force the tn3 tile family
+  NR_OPT_TN3_NI,         // 4 / 8: force the tn3 n-tile
+  NR_OPT_NT_NOWIDE,      // 1: no "wide" NT kernel
+  NR_OPT_NT_NODMA,       // 1: no LDS-DMA NT kernel
+  NR_OPT_DMA_MIN_K,      // smallest K that takes the LDS-DMA NT kernel (default 192)
+  NR_OPT_DMA_WM2_ALL,    // 1: 128-row DMA tiles for every N
+  NR_OPT_COUNT
+};
+int nr_opt(int which);
+
 // ---- per-kernel timing scope (host); no-op unless nr_prof_enable(1) ----------------------
 struct NrProfScope {
   int idx;

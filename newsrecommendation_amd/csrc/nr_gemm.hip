@@ -1326,7 +1326,7 @@ int launch_nt_dma_p(const RowSrc& A, const void* B, int ldb, int M, int N, int K
   // column chunk (att_fc1: 0.47 -> 0.41 ms); with several chunks the smaller tile re-reads A more often and loses
   // (QKV projection: 1.45 -> 1.57 ms)
   constexpr bool fits2 = 3 * (8 + NT16) * 1024 <= 78 * 1024;
-  static const bool wm2_all = getenv("NR_DMA_WM2_ALL") != nullptr;
+  const bool wm2_all = nr_opt(NR_OPT_DMA_WM2_ALL) != 0;
   if (fits2 && (N <= NT16 * 16 || wm2_all)) return launch_nt_dma_w<EPI, NT16, PK, 2>(A, B, ldb, M, N, K, ep, stream);
   return launch_nt_dma_w<EPI, NT16, PK, 4>(A, B, ldb, M, N, K, ep, stream);
 }
@@ -1543,7 +1543,7 @@ int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw
   // ONE round of resident workgroups (256 CUs x 1 or 2), splits a multiple of the 8 XCDs, >= 16 slabs per split.
   // Measured at N=1200, K=304: 1 / 2 / 3 / 4 rounds = 1.03 / 1.14 / 1.25 / 1.34 ms -- every split pays a ring fill and
   // an fp32 atomic epilogue over the whole [N, K] tile, so fewer, longer splits win.
-  static const int force_rounds = [] { const char* e = getenv("NR_TN3_ROUNDS"); return e ? atoi(e) : 0; }();
+  const int force_rounds = nr_opt(NR_OPT_TN3_ROUNDS);
   const int resident = 256 * (WK == 4 ? 1 : 2), rounds = force_rounds ? force_rounds : 1;
   int nsplit = (resident * rounds / ntile / 8) * 8;     // rounded down: never a few workgroups left for an extra round
   if (nsplit < 8) nsplit = 8;
@@ -1563,14 +1563,14 @@ int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw
 
 // rows a multiple of the 32-row slab, at least 8 columns on both sides (tail clamping), 16-byte aligned rows
 bool eligible(int ldc, int ldx, int M, int N, int K) {
-  static const bool off = getenv("NR_NO_TN3") != nullptr;
+  const bool off = nr_opt(NR_OPT_NO_TN3) != 0;
   // long contractions only: at the user level (M = 25 600) the ring fill per split costs more than it hides (0.31 vs 0.18 ms)
   return !off && M % TBM == 0 && M >= 200000 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0 && ldc % 8 == 0 && ldx % 8 == 0;
 }
 int launch(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
            int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr) {
-  static const int force = [] { const char* e = getenv("NR_TN3_WK"); return e ? atoi(e) : 0; }();
-  static const int force_ni = [] { const char* e = getenv("NR_TN3_NI"); return e ? atoi(e) : 0; }();
+  const int force = nr_opt(NR_OPT_TN3_WK);
+  const int force_ni = nr_opt(NR_OPT_TN3_NI);
   const bool wide = force ? force == 4 : (K > 160 && ((K + 319) / 320) * 320 * 100 <= K * 115);
   if (wide) {
     const bool big = force_ni ? force_ni == 8 : N > 256;
@@ -1852,11 +1852,11 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
   //                         1.42 ms vs 1.92 ms tiled; att_fc1 K=400; dX K=1200), packed bf16 epilogue
   //   N <= 208, small K   : "wide" kernel, all N columns per workgroup (A read once)
   //   otherwise           : 128 x 128 tiled kernel with the packed bf16 epilogue (pooling dX, K=200: 0.77 vs 1.02 ms)
-  static const bool no_wide = getenv("NR_NT_NOWIDE") != nullptr;
-  static const bool no_dma = getenv("NR_NT_NODMA") != nullptr;
+  const bool no_wide = nr_opt(NR_OPT_NT_NOWIDE) != 0;
+  const bool no_dma = nr_opt(NR_OPT_NT_NODMA) != 0;
   const int kr32 = (K + 31) / 32 * 32;
   const bool dense_bf16 = dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0 && ep.rows_out == nullptr;
-  static const int dma_min_k = getenv("NR_DMA_MIN_K") ? atoi(getenv("NR_DMA_MIN_K")) : 192;
+  const int dma_min_k = nr_opt(NR_OPT_DMA_MIN_K);
   if (dense_bf16 && !no_dma && K >= dma_min_k && ldb >= kr32 && A.ld >= K) {
     // B must be zero beyond K up to the next multiple of 32 (nr_cast_pad with such an ld guarantees it)
     // with row compaction only the live rows (count on the device) are multiplied: M is then an upper bound
@@ -2018,7 +2018,7 @@ int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float
   NR_CHECK_ARG(N % ch == 0 && K % ch == 0 && ldc % ch == 0 && A.ld % ch == 0, "gemm_tn: N=%d K=%d ldc=%d lda=%d must be multiples of %d",
                N, K, ldc, A.ld, ch);
   NR_CHECK_ARG(((uintptr_t)A.base & 15) == 0 && ((uintptr_t)dC & 15) == 0, "gemm_tn: operands must be 16-byte aligned");
-  static const bool tn_v1 = getenv("NR_TN_V1") != nullptr;
+  const bool tn_v1 = nr_opt(NR_OPT_TN_V1) != 0;
   if (!tn_v1 && dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0) {
     if (tn3::eligible(ldc, A.ld, M, N, K)) {
       NrProfScope ps(stream, "gemm_tn3[bf16,M=%d,N=%d,K=%d]", M, N, K);

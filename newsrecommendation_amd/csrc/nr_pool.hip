@@ -424,11 +424,12 @@ __global__ void pack_conv_w_kernel(const float* __restrict__ w, int N, int D, T*
   }
 }
 
-__global__ void unpack_conv_dw_kernel(const float* __restrict__ dwp, int N, int D, int Dp, float* __restrict__ dw) {
+__global__ void unpack_conv_dw_kernel(const float* __restrict__ dwp, int N, int D, int Dp, float* __restrict__ dw, int accumulate) {
   const size_t total = (size_t)N * D * 3;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int n = (int)(i / (3 * D)), r = (int)(i - (size_t)n * 3 * D), d = r / 3, tap = r - d * 3;
-    dw[i] = dwp[(size_t)n * 3 * Dp + tap * Dp + d];
+    const float v = dwp[(size_t)n * 3 * Dp + tap * Dp + d];
+    dw[i] = accumulate ? dw[i] + v : v;
   }
 }
 
@@ -514,6 +515,7 @@ int nr_cast_pad(const float* src, int rows, int cols, int ld_src, void* dst, int
                 nr_stream_t stream) {
   NR_CHECK_ARG(src && dst && rows > 0 && cols > 0, "cast_pad: null/empty");
   NR_CHECK_ARG(ld_dst >= (transpose ? rows : cols) && ld_src >= cols, "cast_pad: leading dimensions too small");
+  NR_DEVICE_GUARD(stream, dst);
   const size_t total = (size_t)(transpose ? cols : rows) * ld_dst;
   hipStream_t s = (hipStream_t)stream;
   NrProfScope ps(s, "cast_pad[rows=%d,cols=%d]", rows, cols);
@@ -527,6 +529,7 @@ int nr_cast_pad(const float* src, int rows, int cols, int ld_src, void* dst, int
 
 int nr_pack_conv_w(const float* w, int N, int D, void* dst, int Dp, int dtype, nr_stream_t stream) {
   NR_CHECK_ARG(w && dst && N > 0 && D > 0 && Dp >= D, "pack_conv_w: bad arguments");
+  NR_DEVICE_GUARD(stream, dst);
   const size_t total = (size_t)N * 3 * Dp;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == NR_BF16)
@@ -537,9 +540,10 @@ int nr_pack_conv_w(const float* w, int N, int D, void* dst, int Dp, int dtype, n
   return NR_OK;
 }
 
-int nr_unpack_conv_dw(const float* dw_pack, int N, int D, int Dp, float* dw, nr_stream_t stream) {
+int nr_unpack_conv_dw(const float* dw_pack, int N, int D, int Dp, float* dw, int accumulate, nr_stream_t stream) {
   NR_CHECK_ARG(dw_pack && dw && N > 0 && D > 0 && Dp >= D, "unpack_conv_dw: bad arguments");
-  hipLaunchKernelGGL(unpack_conv_dw_kernel, dim3(grid_for((size_t)N * D * 3)), dim3(256), 0, (hipStream_t)stream, dw_pack, N, D, Dp, dw);
+  NR_DEVICE_GUARD(stream, dw);
+  hipLaunchKernelGGL(unpack_conv_dw_kernel, dim3(grid_for((size_t)N * D * 3)), dim3(256), 0, (hipStream_t)stream, dw_pack, N, D, Dp, dw, accumulate);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -547,6 +551,7 @@ int nr_unpack_conv_dw(const float* dw_pack, int N, int D, int Dp, float* dw, nr_
 int nr_embed_gather_fwd(const void* table, int ld_table, int dtype, const int32_t* ids, int n_ids, int ids_stride,
                         int cols, float* out, int ld_out, nr_stream_t stream) {
   NR_CHECK_ARG(table && ids && out, "embed_gather_fwd: null pointer");
+  NR_DEVICE_GUARD(stream, out);
   if (n_ids == 0) return NR_OK;
   NR_CHECK_ARG(n_ids > 0 && cols > 0 && ids_stride >= 1, "embed_gather_fwd: bad sizes");
   hipStream_t s = (hipStream_t)stream;
@@ -561,6 +566,7 @@ int nr_embed_gather_fwd(const void* table, int ld_table, int dtype, const int32_
 int nr_embed_gather_bwd(const float* dout, int ld_dout, const int32_t* ids, int n_ids, int ids_stride, int cols,
                         float* dtable, int ld_dtable, nr_stream_t stream) {
   NR_CHECK_ARG(dout && ids && dtable, "embed_gather_bwd: null pointer");
+  NR_DEVICE_GUARD(stream, dtable);
   if (n_ids == 0) return NR_OK;
   hipLaunchKernelGGL(gather_bwd_kernel, dim3((n_ids + 3) / 4), dim3(256), 0, (hipStream_t)stream, dout, ld_dout, ids, n_ids, ids_stride, cols, dtable, ld_dtable);
   NR_CHECK_LAUNCH();
@@ -571,6 +577,7 @@ int nr_pad_blend_fwd(const float* x, const float* mask, const float* pad, void* 
                      nr_stream_t stream) {
   NR_CHECK_ARG(x && out && n > 0 && L > 0 && N > 0, "pad_blend_fwd: null/empty");
   NR_CHECK_ARG(mask == nullptr || pad != nullptr, "pad_blend_fwd: mask without pad_doc");
+  NR_DEVICE_GUARD(stream, out);
   const size_t rows = (size_t)n * L;
   hipStream_t s = (hipStream_t)stream;
   NrProfScope ps(s, "pad_blend_fwd[n=%d,L=%d,N=%d]", n, L, N);
@@ -585,6 +592,7 @@ int nr_pad_blend_fwd(const float* x, const float* mask, const float* pad, void* 
 int nr_pad_blend_bwd(const void* dout, const float* mask, float* dx, float* dpad, int n, int L, int N, int dtype,
                      nr_stream_t stream) {
   NR_CHECK_ARG(dout && dx && n > 0 && L > 0 && N > 0, "pad_blend_bwd: null/empty");
+  NR_DEVICE_GUARD(stream, dx);
   const int rows = n * L, rpb = 32;
   hipStream_t s = (hipStream_t)stream;
   NrProfScope ps(s, "pad_blend_bwd[n=%d,L=%d,N=%d]", n, L, N);
@@ -600,6 +608,7 @@ int nr_score_ce_fwd(const float* cand, int ld_cand, const float* user, const int
                     float* lossvec, int B, int C, int N, nr_stream_t stream) {
   NR_CHECK_ARG(cand && user && label && score && loss && lossvec, "score_ce_fwd: null pointer");
   NR_CHECK_ARG(B > 0 && C >= 1 && C <= 64 && N > 0, "score_ce_fwd: B=%d C=%d (1..64) N=%d", B, C, N);
+  NR_DEVICE_GUARD(stream, score);
   hipStream_t s = (hipStream_t)stream;
   NrProfScope ps(s, "score_ce_fwd[B=%d,C=%d,N=%d]", B, C, N);
   hipLaunchKernelGGL(score_ce_fwd_kernel, dim3(B), dim3(64), 0, s, cand, ld_cand, user, label, score, lossvec, C, N);
@@ -613,6 +622,7 @@ int nr_score_ce_bwd(const float* cand, int ld_cand, const float* user, const int
                     nr_stream_t stream) {
   NR_CHECK_ARG(cand && user && label && score && dcand && duser, "score_ce_bwd: null pointer");
   NR_CHECK_ARG(B > 0 && C >= 1 && C <= 64 && N > 0, "score_ce_bwd: B=%d C=%d (1..64) N=%d", B, C, N);
+  NR_DEVICE_GUARD(stream, dcand);
   NrProfScope ps((hipStream_t)stream, "score_ce_bwd[B=%d,C=%d,N=%d]", B, C, N);
   hipLaunchKernelGGL(score_ce_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, cand, ld_cand, user, label, score, gloss, gscore, 1.0f / (float)B, dcand, ld_dcand, duser, C, N);
   NR_CHECK_LAUNCH();
@@ -622,6 +632,7 @@ int nr_score_ce_bwd(const float* cand, int ld_cand, const float* user, const int
 int nr_score_eval(const float* news_vecs, int ld_news, const int32_t* cand_ids, const int32_t* imp_of, const float* user,
                   int ld_user, float* score, int n_cand, int N, nr_stream_t stream) {
   NR_CHECK_ARG(news_vecs && cand_ids && imp_of && user && score, "score_eval: null pointer");
+  NR_DEVICE_GUARD(stream, score);
   if (n_cand == 0) return NR_OK;
   hipLaunchKernelGGL(score_eval_kernel, dim3((n_cand + 3) / 4), dim3(256), 0, (hipStream_t)stream, news_vecs, ld_news, cand_ids, imp_of, user, ld_user, score, n_cand, N);
   NR_CHECK_LAUNCH();
@@ -630,6 +641,7 @@ int nr_score_eval(const float* news_vecs, int ld_news, const int32_t* cand_ids, 
 
 int nr_dropout_mask(float* out, uint32_t count, float p, uint32_t seed, nr_stream_t stream) {
   NR_CHECK_ARG(out != nullptr, "dropout_mask: null pointer");
+  NR_DEVICE_GUARD(stream, out);
   if (count == 0) return NR_OK;
   const DropCfg d = nr_make_drop(p, seed);
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(count)), dim3(256), 0, (hipStream_t)stream, out, count, d.key, d.thresh);

@@ -90,13 +90,10 @@ class DatasetTrain(IterableDataset):
     def trans_to_nindex(self, nids):
         return [self.news_index[i] if i in self.news_index else 0 for i in nids]       # unknown news -> 0
 
-    def pad_to_fix_len(self, x, fix_length, padding_front=True, padding_value=0):
-        if padding_front:                                                            # keep the LAST fix_length clicks
-            pad_x = [padding_value] * (fix_length - len(x)) + x[-fix_length:]
-            mask = [0] * (fix_length - len(x)) + [1] * min(fix_length, len(x))
-        else:
-            pad_x = x[-fix_length:] + [padding_value] * (fix_length - len(x))
-            mask = [1] * min(fix_length, len(x)) + [0] * (fix_length - len(x))
+    def pad_to_fix_len(self, x, fix_length):
+        """Front padding (the only mode the reference uses, src/dataset.py:17-20): keep the LAST fix_length clicks."""
+        pad_x = [0] * (fix_length - len(x)) + x[-fix_length:]
+        mask = [0] * (fix_length - len(x)) + [1] * min(fix_length, len(x))
         return pad_x, np.array(mask, dtype="float32")
 
     def line_to_indices(self, line):
@@ -136,6 +133,71 @@ class DatasetTest(DatasetTrain):
     def line_mapper(self, line):
         hist, mask, cand, labels = self.line_to_indices(line)
         return self.news_scoring[hist], mask, self.news_scoring[cand], labels
+
+
+class IndexedTrainShard:
+    """Row f1 of SURVEY §8: the integer part of `DatasetTrain` for a WHOLE shard file, parsed once.
+
+    The reference re-parses the shard line by line every epoch inside the training loop (src/dataset.py:26-53, ~10^4
+    lines/s in Python) and ships [H, F] / [1+K, F] feature blocks per sample.  Here the shard becomes four index arrays
+    that are uploaded once; per epoch only the label positions are drawn -- `random.randint(0, npratio)` per line in
+    file order, the reference's own RNG call (src/dataset.py:45), so the (label, sample_news) stream is bit-identical
+    to iterating `DatasetTrain` -- and `ops.assemble_batch` gathers the feature rows on the device.
+
+      hist  [n, H] int32  news indices, front padded (src/dataset.py:17-24,40)      mask [n, H] float32
+      pos   [n]    int32  the clicked news                                           neg  [n, K] int32
+    """
+
+    def __init__(self, filename, news_index, args):
+        H, K = args.user_log_length, args.npratio
+        tr = DatasetTrain(filename, news_index, None, args)
+        hist, mask, pos, neg = [], [], [], []
+        with open(filename) as f:
+            for ln, line in enumerate(f):
+                fld = line.strip().split("\t")
+                h, m = tr.pad_to_fix_len(tr.trans_to_nindex(fld[3].split()), H)
+                p, ng = tr.trans_to_nindex(fld[4].split()), tr.trans_to_nindex(fld[5].split())
+                if len(p) != 1 or len(ng) != K:
+                    raise ValueError(f"{filename}:{ln + 1}: expected 1 positive and {K} negatives per line "
+                                     f"(src/prepare_data.py:31-35 writes such lines), got {len(p)} / {len(ng)}")
+                hist.append(h); mask.append(m); pos.append(p[0]); neg.append(ng)
+        n = len(pos)
+        self.hist = np.asarray(hist, dtype=np.int32).reshape(n, H)
+        self.mask = np.asarray(mask, dtype=np.float32).reshape(n, H)
+        self.pos = np.asarray(pos, dtype=np.int32)
+        self.neg = np.asarray(neg, dtype=np.int32).reshape(n, K)
+        self.npratio = K
+
+    def __len__(self):
+        return self.pos.shape[0]
+
+    def draw_labels(self):
+        """One epoch's label positions, in file order: the `random.randint(0, npratio)` stream of src/dataset.py:45."""
+        K = self.npratio
+        return np.fromiter((random.randint(0, K) for _ in range(len(self))), dtype=np.int64, count=len(self))
+
+
+class IndexedTestShard:
+    """The integer part of `DatasetTest` (src/dataset.py:64-74) for a whole shard: history indices / mask per impression and
+    the variable-length candidate lists in CSR form (cand, label, offsets)."""
+
+    def __init__(self, filename, news_index, args):
+        H = args.user_log_length
+        tr = DatasetTest(filename, news_index, None, args)
+        hist, mask, cand, lab, off = [], [], [], [], [0]
+        with open(filename) as f:
+            for line in f:
+                h, m, c, l = tr.line_to_indices(line)
+                hist.append(h); mask.append(m); cand += c; lab += l.tolist(); off.append(len(cand))
+        n = len(hist)
+        self.hist = np.asarray(hist, dtype=np.int32).reshape(n, H)
+        self.mask = np.asarray(mask, dtype=np.float32).reshape(n, H)
+        self.cand = np.asarray(cand, dtype=np.int32)
+        self.label = np.asarray(lab, dtype=np.int32)
+        self.offsets = np.asarray(off, dtype=np.int32)
+
+    def __len__(self):
+        return self.hist.shape[0]
 
 
 class NewsDataset(Dataset):

@@ -30,15 +30,20 @@ class AttentionPooling(nn.Module):
 
 
 class ScaledDotProductAttention(nn.Module):
-    """src/model/model_utils.py:34-55.  Kept for surface compatibility; the attention core lives in the
-    fused MHSA op, so this module is only a holder of d_k."""
+    """src/model/model_utils.py:34-55.  MultiHeadSelfAttention runs projection + attention as one op and does not go
+    through this module; called on its own it runs the same attention kernels on the given Q, K, V (nr_sdpa_fwd/bwd)."""
 
-    def __init__(self, d_k):
+    def __init__(self, d_k, compute_dtype="fp32"):
         super().__init__()
         self.d_k = d_k
+        self.compute_dtype = compute_dtype
 
     def forward(self, Q, K, V, attn_mask=None):
-        raise NotImplementedError("ScaledDotProductAttention is fused into MultiHeadSelfAttention on this backend")
+        """Q, K, V: [batch, n_heads, L, d_k]; attn_mask: [batch, n_heads, L] (the [batch, L] key mask repeated over
+        heads, :86-87) or [batch, L] -> context [batch, n_heads, L, d_k] in the compute dtype."""
+        if Q.shape[-1] != self.d_k:
+            raise RuntimeError(f"ScaledDotProductAttention(d_k={self.d_k}) got head dim {Q.shape[-1]}")
+        return ops.sdpa(Q, K, V, ops.dtype_code(self.compute_dtype), mask=attn_mask)
 
 
 class MultiHeadSelfAttention(nn.Module):
@@ -52,7 +57,7 @@ class MultiHeadSelfAttention(nn.Module):
         self.W_Q = nn.Linear(d_model, d_k * n_heads)
         self.W_K = nn.Linear(d_model, d_k * n_heads)
         self.W_V = nn.Linear(d_model, d_v * n_heads)
-        self.scaled_dot_product_attn = ScaledDotProductAttention(self.d_k)
+        self.scaled_dot_product_attn = ScaledDotProductAttention(self.d_k, compute_dtype=compute_dtype)
         self.compute_dtype = compute_dtype
         self._initialize_weights()
 
@@ -72,10 +77,11 @@ class MultiHeadSelfAttention(nn.Module):
         x = Q
         if x.dtype != ops.torch_dtype(code):
             x = ops.to_compute(x.float(), code)
-        return ops.mhsa(x, *self._params(), heads=self.n_heads, code=code, mask=mask, p_out=p_out)
+        return ops.mhsa(x, *self._params(), heads=self.n_heads, code=code, mask=mask, p_out=p_out,
+                        flat=getattr(self, "_nr_flat", None))
 
     def forward_gather(self, ids, table, mask=None, p_in=0.0, p_out=0.0):
         """Embedding lookup + dropout + MHSA + dropout in one op: ids int32 [batch, L] into `table` [V, d_model]."""
         code = ops.dtype_code(self.compute_dtype)
         return ops.mhsa(None, *self._params(), heads=self.n_heads, code=code, mask=mask, ids=ids, table=table,
-                        p_in=p_in, p_out=p_out)
+                        p_in=p_in, p_out=p_out, flat=getattr(self, "_nr_flat", None))

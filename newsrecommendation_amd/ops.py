@@ -7,6 +7,8 @@ the GPU: there is no CPU fallback (a RuntimeError is raised instead).
 from __future__ import annotations
 
 import ctypes as C
+import os
+import weakref
 from typing import Optional
 
 import torch
@@ -50,6 +52,60 @@ def _need_gpu(*ts) -> None:
                                f"got a tensor on {t.device}")
 
 
+# Test hook: when True, buffers the kernels are documented to leave partly unwritten (qkv / dqkv rows of all-padding
+# sequences) are pre-filled with NaN, so a read of an unwritten row poisons the result instead of passing silently.
+POISON_WORKSPACES = False
+
+
+def _scratch(*shape, dtype, device):
+    t = torch.empty(*shape, dtype=dtype, device=device)
+    if POISON_WORKSPACES and t.is_floating_point():
+        t.fill_(float("nan"))
+    return t
+
+
+# Index validation (what torch.nn.functional.embedding / cross_entropy raise IndexError for).  The kernels trust their
+# indices; with CHECK_INDICES on (env NR_CHECK_INDICES=1, or set the attribute) every id / label tensor is range-checked
+# on the device before use, at the price of one host synchronisation per check.
+CHECK_INDICES = os.environ.get("NR_CHECK_INDICES", "0") not in ("", "0")
+
+
+def check_ids(ids: torch.Tensor, rows: int, what: str = "index") -> None:
+    """Raise IndexError if any entry of the int32 tensor `ids` (any 1-D stride) lies outside [0, rows)."""
+    if ids.numel() == 0:
+        return
+    bad = torch.zeros(1, dtype=torch.int32, device=ids.device)
+    if ids.dim() == 1:
+        count, stride, base = ids.shape[0], ids.stride(0), ids
+    else:
+        base = ids.contiguous()
+        count, stride = base.numel(), 1
+    check(_lib.lib().nr_check_ids(ptr(base), count, stride, int(rows), ptr(bad), _stream()), "nr_check_ids")
+    n = int(bad.item())
+    if n:
+        raise IndexError(f"{what}: {n} entries outside [0, {rows})")
+
+
+def check_labels(label: torch.Tensor, classes: int) -> None:
+    bad = torch.zeros(1, dtype=torch.int32, device=label.device)
+    check(_lib.lib().nr_check_labels(ptr(label), label.numel(), int(classes), ptr(bad), _stream()), "nr_check_labels")
+    n = int(bad.item())
+    if n:
+        raise IndexError(f"label: {n} entries outside [0, {classes})")
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    """A workspace of the size the library asked for (bytes -> int32 elements)."""
+    return torch.empty((int(nbytes) + 3) // 4, dtype=torch.int32, device=device)
+
+
+def grad_target(p):
+    """The preallocated gradient view of a parameter that lives in a flat bucket (parallel.FlatBucket sets
+    `_nr_grad`), or None.  Backward passes ACCUMULATE into such a view directly -- the kernels add into their dW / db /
+    dtable outputs anyway -- and hand autograd None for that parameter: no per-call zero fill, no AccumulateGrad copy."""
+    return getattr(p, "_nr_grad", None) if p is not None else None
+
+
 def draw_seed() -> int:
     """A 31-bit dropout seed from torch's CPU generator (reproducible under torch.manual_seed)."""
     return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
@@ -71,11 +127,33 @@ def pack(src: torch.Tensor, code: int, transpose: bool = False, ld: Optional[int
 
 
 class _TableCache:
-    """Compute-dtype copies of embedding tables, refreshed when the fp32 master changes
-    (tensor version counter), so a frozen table is packed once."""
+    """Compute-dtype copies of embedding tables, refreshed when the fp32 master changes (tensor version counter,
+    storage pointer, shape), so a frozen table is packed once.
+
+    An entry lives exactly as long as the Parameter it was packed from: the key is `id(weight)`, and a
+    `weakref.finalize` on that Parameter evicts the entry when the Parameter is collected, so a recycled `id()` can
+    never be served another model's table and dead tables do not stay pinned in HBM.  A held weak reference is
+    compared on every hit as well.  Writes that bypass autograd's version counter (`weight.data.copy_(...)`, as a
+    parameter broadcast does) need an explicit `table_cache.invalidate(weight)`."""
 
     def __init__(self):
         self._c = {}
+        self._watched = set()            # ids of parameters that carry an eviction finalizer
+
+    def _drop(self, wid):
+        for key in [k for k in self._c if k[0] == wid]:
+            del self._c[key]
+
+    def _evict(self, wid):                # the parameter died
+        self._drop(wid)
+        self._watched.discard(wid)
+
+    def invalidate(self, weight=None):
+        """Forget the packed copy of `weight` (all copies if None); the next use re-packs from the fp32 master."""
+        if weight is None:
+            self._c.clear()
+        else:
+            self._drop(id(weight))
 
     def get(self, weight: torch.Tensor, code: int, row_cols: Optional[int] = None) -> torch.Tensor:
         w = weight.detach()
@@ -85,8 +163,11 @@ class _TableCache:
         key = (id(weight), code, cols)
         ent = self._c.get(key)
         sig = (weight._version, w.data_ptr(), tuple(w.shape))
-        if ent is None or ent[0] != sig:
-            ent = (sig, pack(w.reshape(-1, cols), code))
+        if ent is None or ent[0] != sig or ent[2]() is not weight:
+            if id(weight) not in self._watched:
+                self._watched.add(id(weight))
+                weakref.finalize(weight, self._evict, id(weight))
+            ent = (sig, pack(w.reshape(-1, cols), code), weakref.ref(weight))
             self._c[key] = ent
         return ent[1]
 
@@ -117,9 +198,13 @@ class MHSAFunction(Function):
             if src.dtype != torch_dtype(code):
                 raise RuntimeError(f"dense MHSA input must be {torch_dtype(code)}, got {src.dtype}")
         ldx = src.shape[-1]
-        wcat = torch.cat([wq, wk, wv], dim=0)
+        flat = cfg.get("flat")             # W_Q|W_K|W_V (and the biases) adjacent in a flat bucket: no concatenation
+        if flat is not None:
+            wcat, b_p = flat["w"], flat["b"]
+        else:
+            wcat = torch.cat([wq, wk, wv], dim=0)
+            b_p = torch.cat([bq, bk, bv]).detach().float().contiguous()
         w_p = pack(wcat, code)
-        b_p = torch.cat([bq, bk, bv]).detach().float().contiguous()
         mask_c = mask.contiguous().float() if mask is not None else None
         dev = wq.device
         y = torch.empty(n, L, N, dtype=torch_dtype(code), device=dev)
@@ -128,16 +213,18 @@ class MHSAFunction(Function):
         keep_rows = gather and any(ctx.needs_input_grad[1:7])
         Kp = round_up(d_model, ch)
         x_rows = torch.empty(n * L, Kp, dtype=torch_dtype(code), device=dev) if keep_rows else None
-        # scratch for the device-side compaction of non-padding rows (forward: live rows, their ids, padding rows)
-        row_ws = torch.empty(3 * n * L + 3 * n + (n * L) // 32 + 32, dtype=torch.int32, device=dev) if keep_rows and code == _lib.NR_BF16 else None
         d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=d_head, dtype=code,
                           src_kind=NR_SRC_GATHER if gather else NR_SRC_DENSE, x=ptr(src), ldx=ldx, ids=ptr(ids),
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
-                          x_rows=ptr(x_rows), ld_rows=Kp, row_ws=ptr(row_ws))
+                          x_rows=ptr(x_rows), ld_rows=Kp)
+        # scratch for the device-side compaction of non-padding rows (forward: live rows, their ids, padding rows;
+        # backward: live slabs, sequence list) -- sized by the library
+        row_ws = _ws(_lib.lib().nr_mhsa_workspace_bytes(C.byref(d)), dev) if keep_rows and code == _lib.NR_BF16 else None
+        d.row_ws, d.row_ws_bytes = ptr(row_ws), (row_ws.numel() * 4 if row_ws is not None else 0)
         # the fused title-level kernel keeps Q|K|V on chip: without a backward they are never written to HBM
         fused = bool(_lib.lib().nr_mhsa_fwd_fused(C.byref(d)))
-        qkv = None if (fused and not need_bwd) else torch.empty(n * L, 3 * N, dtype=torch_dtype(code), device=dev)
+        qkv = None if (fused and not need_bwd) else _scratch(n * L, 3 * N, dtype=torch_dtype(code), device=dev)
         check(_lib.lib().nr_mhsa_fwd(C.byref(d), ptr(qkv), ptr(y), _stream()), "nr_mhsa_fwd")
         ctx.cfg, ctx.dims = cfg, (n, L, N, d_model, heads, d_head, ldx, gather)
         ctx.row_ws = row_ws      # the backward attention and the table-gradient GEMM reuse the compaction
@@ -153,44 +240,116 @@ class MHSAFunction(Function):
         dy = dy.contiguous()
         if dy.dtype != torch_dtype(code):
             dy = dy.to(torch_dtype(code))
-        dqkv = torch.empty_like(qkv)
-        flat = torch.zeros(3 * N * d_model + 3 * N, dtype=torch.float32, device=dev)     # dw | db, one fill
-        dw, db = flat[:3 * N * d_model].view(3 * N, d_model), flat[3 * N * d_model:]
+        dqkv = _scratch(*qkv.shape, dtype=qkv.dtype, device=dev)
+        bucket = cfg.get("flat")
+        if bucket is not None:
+            dw, db = bucket["gw"], bucket["gb"]                    # accumulated in place
+        else:
+            flat = torch.zeros(3 * N * d_model + 3 * N, dtype=torch.float32, device=dev)     # dw | db, one fill
+            dw, db = flat[:3 * N * d_model].view(3 * N, d_model), flat[3 * N * d_model:]
         need_x = ctx.needs_input_grad[0]
         dx = dtable = w_t = None
         row_ws = getattr(ctx, "row_ws", None)          # what the forward compacted (padding rows of qkv were never written)
         ws_ready = row_ws is not None
-        if need_x:
-            w_t = pack(wcat, code, transpose=True)                     # [d_model, 3N]
-            if gather:
-                dtable = torch.zeros(cfg["table_shape"], dtype=torch.float32, device=dev)
-                if row_ws is None:
-                    row_ws = torch.empty(3 * n * L + 3 * n + (n * L) // 32 + 32, dtype=torch.int32, device=dev)     # live-row compaction scratch
-            else:
-                dx = torch.empty(n, L, ldx, dtype=torch_dtype(code), device=dev)
         d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=d_head, dtype=code,
                           src_kind=NR_SRC_GATHER if gather else NR_SRC_DENSE, x=ptr(src), ldx=ldx, ids=ptr(ids),
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
-                          x_rows=ptr(x_rows), ld_rows=x_rows.shape[1] if x_rows is not None else 0, row_ws=ptr(row_ws),
+                          x_rows=ptr(x_rows), ld_rows=x_rows.shape[1] if x_rows is not None else 0,
                           row_ws_ready=int(ws_ready))
+        if need_x:
+            w_t = pack(wcat, code, transpose=True)                     # [d_model, 3N]
+            if gather:
+                dtable = cfg.get("table_grad")
+                if dtable is None:
+                    dtable = torch.zeros(cfg["table_shape"], dtype=torch.float32, device=dev)
+                if row_ws is None:
+                    row_ws = _ws(_lib.lib().nr_mhsa_workspace_bytes(C.byref(d)), dev)     # live-row compaction scratch
+            else:
+                dx = torch.empty(n, L, ldx, dtype=torch_dtype(code), device=dev)
+        d.row_ws, d.row_ws_bytes = ptr(row_ws), (row_ws.numel() * 4 if row_ws is not None else 0)
         check(_lib.lib().nr_mhsa_bwd(C.byref(d), ptr(qkv), ptr(dy), ptr(dqkv), ptr(w_t), w_t.shape[1] if w_t is not None else 0,
                                      ptr(dw), ptr(db), ptr(dx), ptr(dtable), _stream()), "nr_mhsa_bwd")
-        gx = dtable if gather else dx
+        gx = (None if cfg.get("table_grad") is not None else dtable) if gather else dx
+        if bucket is not None:
+            return (gx, None, None, None, None, None, None, None, None, None)
         return (gx, dw[:N], db[:N], dw[N:2 * N], db[N:2 * N], dw[2 * N:], db[2 * N:], None, None, None)
 
 
-def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int, code: int, mask=None, ids=None, table=None, p_in=0.0, p_out=0.0):
-    """Dense: x [n, L, d_model] (compute dtype).  Gather: ids int32 [n, L] + fp32 `table` parameter."""
+def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int, code: int, mask=None, ids=None, table=None, p_in=0.0, p_out=0.0, flat=None):
+    """Dense: x [n, L, d_model] (compute dtype).  Gather: ids int32 [n, L] + fp32 `table` parameter.
+    flat: {"w": [3N, d_model], "b": [3N], "gw", "gb"} views of a flat parameter / gradient bucket (parallel.FlatBucket)."""
     cfg = dict(code=code, heads=heads, p_in=float(p_in), p_out=float(p_out),
                seed_in=draw_seed() if p_in > 0 else 0, seed_out=draw_seed() if p_out > 0 else 0)
+    if flat is not None:
+        cfg["flat"] = flat
     if ids is not None:
         if ids.dtype != torch.int32:
             ids = ids.to(torch.int32)
+        if CHECK_INDICES:
+            check_ids(ids, table.shape[0], "token id")
         cfg["table_packed"] = table_cache.get(table, code)
         cfg["table_shape"] = tuple(table.shape)
+        if table.requires_grad and torch.is_grad_enabled():
+            cfg["table_grad"] = grad_target(table)
         return MHSAFunction.apply(table, wq, bq, wk, bk, wv, bv, ids, mask, cfg)
+    ch = chunk(code)
+    if x.shape[-1] % ch:
+        # d_model not a multiple of the 16-byte operand chunk: zero-pad the feature axis of x and of the weights (torch
+        # plumbing on a rare shape; autograd slices the gradients back)
+        pad = ch - x.shape[-1] % ch
+        cfg.pop("flat", None)               # the padded weights are temporaries: gradients go through autograd
+        x = torch.nn.functional.pad(x, (0, pad))
+        wq, wk, wv = (torch.nn.functional.pad(w, (0, pad)) for w in (wq, wk, wv))
     return MHSAFunction.apply(x, wq, bq, wk, bk, wv, bv, None, mask, cfg)
+
+
+# ------------------------------------------------------------------------------------------ attention core alone
+class SDPAFunction(Function):
+    """ScaledDotProductAttention.forward, src/model/model_utils.py:39-55, on packed projections [n*L, 3N]."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, n, L, heads, d_head, code):
+        _need_gpu(qkv, mask)
+        N = heads * d_head
+        mask_c = mask.contiguous().float() if mask is not None else None
+        y = torch.empty(n * L, N, dtype=torch_dtype(code), device=qkv.device)
+        check(_lib.lib().nr_sdpa_fwd(ptr(qkv), ptr(mask_c), ptr(y), n, L, heads, d_head, code, 0.0, 0, _stream()), "nr_sdpa_fwd")
+        ctx.dims = (n, L, heads, d_head, code)
+        ctx.save_for_backward(qkv, mask_c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        qkv, mask_c = ctx.saved_tensors
+        n, L, heads, d_head, code = ctx.dims
+        dy = dy.contiguous()
+        if dy.dtype != torch_dtype(code):
+            dy = dy.to(torch_dtype(code))
+        dqkv = torch.empty_like(qkv)
+        check(_lib.lib().nr_sdpa_bwd(ptr(qkv), ptr(mask_c), ptr(dy), ptr(dqkv), n, L, heads, d_head, code, 0.0, 0, _stream()),
+              "nr_sdpa_bwd")
+        return dqkv, None, None, None, None, None, None
+
+
+def sdpa(Q, K, V, code: int, mask=None):
+    """Q, K, V: [n, h, L, d] (any strides, e.g. the transposed views of src/model/model_utils.py:89-91); mask: [n, L], or the
+    reference's per-head expansion [n, h, L] of it (:86-87) -> [n, h, L, d].  The three tensors are packed into the
+    token-major [n*L, 3*h*d] layout of the kernels (torch plumbing), the attention itself runs in libnrhip."""
+    _need_gpu(Q, K, V, mask)
+    n, h, L, d = Q.shape
+    if K.shape != Q.shape or V.shape != Q.shape:
+        raise RuntimeError(f"sdpa: Q/K/V shapes differ: {tuple(Q.shape)}, {tuple(K.shape)}, {tuple(V.shape)} (d_k must equal d_v)")
+    if mask is not None and mask.dim() == 3:
+        if mask.stride(1) != 0 and not bool((mask == mask[:, :1]).all()):
+            raise NotImplementedError("sdpa: per-head attention masks do not occur in the reference (the mask is the [n, L] key "
+                                      "mask repeated over heads, src/model/model_utils.py:86-87) and are not supported")
+        mask = mask[:, 0]
+    td = torch_dtype(code)
+    # [n, h, L, d] x 3 -> [n, L, 3, h, d] -> [n*L, 3*h*d]
+    qkv = torch.stack([t.to(td).permute(0, 2, 1, 3) for t in (Q, K, V)], dim=2).reshape(n * L, 3 * h * d)
+    y = SDPAFunction.apply(qkv, mask, n, L, h, d, code)
+    return y.view(n, L, h, d).permute(0, 2, 1, 3)
 
 
 # ------------------------------------------------------------------------------------------ pooling
@@ -216,6 +375,7 @@ class PoolFunction(Function):
                           b1=ptr(b1_c), w2=ptr(w2_c), b2=ptr(b2_c))
         check(_lib.lib().nr_additive_pool_fwd(C.byref(d), ptr(e), ptr(alpha), ptr(out), N, _stream()), "nr_additive_pool_fwd")
         ctx.code, ctx.dims = code, (n, L, N, q)
+        ctx.targets = tuple(grad_target(p) for p in (w1, b1, w2, b2)) if torch.is_grad_enabled() else (None,) * 4
         ctx.save_for_backward(x, mask_c, w1_p, b1_c, w2_c, b2_c, e, alpha, w1)
         return out
 
@@ -227,16 +387,23 @@ class PoolFunction(Function):
         g = g.contiguous().float()
         w1_t = pack(w1, code, transpose=True) if ctx.needs_input_grad[0] else None    # [N, q]
         dpre = torch.empty_like(e)
-        partial = torch.empty(n * (q + 1), dtype=torch.float32, device=dev)     # one row per workgroup (<= n of them)
-        # one zero fill for the four accumulated gradients (views of a flat buffer; q*N and q are multiples of 4)
-        flat = torch.zeros(q * N + 2 * q + 4, dtype=torch.float32, device=dev)
-        dw1, db1, dw2, db2 = flat[:q * N].view(q, N), flat[q * N:q * N + q], flat[q * N + q:q * N + 2 * q], flat[q * N + 2 * q:q * N + 2 * q + 1]
+        direct = all(t is not None for t in ctx.targets)
+        if direct:
+            dw1, db1, dw2, db2 = ctx.targets                      # views of the flat gradient bucket, accumulated in place
+        else:
+            # one zero fill for the four accumulated gradients (views of a flat buffer; q*N and q are multiples of 4)
+            flat = torch.zeros(q * N + 2 * q + 4, dtype=torch.float32, device=dev)
+            dw1, db1, dw2, db2 = flat[:q * N].view(q, N), flat[q * N:q * N + q], flat[q * N + q:q * N + 2 * q], flat[q * N + 2 * q:q * N + 2 * q + 1]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         d = _lib.PoolDesc(n=n, L=L, N=N, q=q, dtype=code, x=ptr(x), mask=ptr(mask_c), w1=ptr(w1_p), ldw1=w1_p.shape[1],
                           b1=ptr(b1_c), w2=ptr(w2_c), b2=ptr(b2_c))
+        partial = _ws(_lib.lib().nr_pool_workspace_bytes(C.byref(d)), dev)      # per-workgroup partial rows + slab scratch
+        d.partial_bytes = partial.numel() * 4
         check(_lib.lib().nr_additive_pool_bwd(C.byref(d), ptr(e), ptr(alpha), ptr(g), N, ptr(w1_t),
                                               w1_t.shape[1] if w1_t is not None else 0, ptr(dpre), ptr(partial), ptr(dw1),
                                               ptr(db1), ptr(dw2), ptr(db2), ptr(dx), _stream()), "nr_additive_pool_bwd")
+        if direct:
+            return dx, None, None, None, None, None, None
         return dx, dw1, db1, dw2.view(1, q), db2, None, None
 
 
@@ -259,6 +426,7 @@ class BlendFunction(Function):
         out = torch.empty(n, L, N, dtype=torch_dtype(code), device=x.device)
         check(_lib.lib().nr_pad_blend_fwd(ptr(x), ptr(mask_c), ptr(pad_c), ptr(out), n, L, N, code, _stream()), "nr_pad_blend_fwd")
         ctx.code, ctx.dims, ctx.pad_shape = code, (n, L, N), (tuple(pad.shape) if pad is not None else None)
+        ctx.pad_target = grad_target(pad) if torch.is_grad_enabled() else None
         ctx.save_for_backward(mask_c)
         return out
 
@@ -270,8 +438,11 @@ class BlendFunction(Function):
         if dout.dtype != torch_dtype(ctx.code):
             dout = dout.to(torch_dtype(ctx.code))
         dx = torch.empty(n, L, N, dtype=torch.float32, device=dout.device)
-        dpad = torch.zeros(N, dtype=torch.float32, device=dout.device) if mask_c is not None else None
+        direct = ctx.pad_target is not None and mask_c is not None
+        dpad = ctx.pad_target if direct else (torch.zeros(N, dtype=torch.float32, device=dout.device) if mask_c is not None else None)
         check(_lib.lib().nr_pad_blend_bwd(ptr(dout), ptr(mask_c), ptr(dx), ptr(dpad), n, L, N, ctx.code, _stream()), "nr_pad_blend_bwd")
+        if direct:
+            return dx, None, None, None
         return dx, None, (dpad.view(ctx.pad_shape) if dpad is not None and ctx.pad_shape is not None else None), None
 
 
@@ -318,6 +489,8 @@ class ScoreCEFunction(Function):
 
 
 def score_ce(cand, user, label):
+    if CHECK_INDICES:
+        check_labels(label.contiguous().to(torch.int64), cand.shape[1])
     return ScoreCEFunction.apply(cand, user, label)
 
 
@@ -348,6 +521,7 @@ class ConvFunction(Function):
         ctx.cfg, ctx.dims = cfg, (n, T, D, Dp, N, stride)
         ctx.ids = ids                                   # keeps the (possibly strided) id view alive
         ctx.x_rows = x_rows if any(ctx.needs_input_grad[:2]) else None
+        ctx.targets = (grad_target(w), grad_target(b)) if torch.is_grad_enabled() else (None, None)
         ctx.save_for_backward(table_p, w_p, b_c)
         return y
 
@@ -360,14 +534,18 @@ class ConvFunction(Function):
         if dy.dtype != torch_dtype(code):
             dy = dy.to(torch_dtype(code))
         dwp = torch.zeros(N, 3 * Dp, dtype=torch.float32, device=dev)
-        db = torch.zeros(N, dtype=torch.float32, device=dev)
-        bwd_ws = torch.empty(n + (n * T) // 32 + 16, dtype=torch.int32, device=dev) if ctx.x_rows is not None else None
+        direct = all(t is not None for t in ctx.targets)
+        db = ctx.targets[1] if direct else torch.zeros(N, dtype=torch.float32, device=dev)
         d = _lib.ConvDesc(n=n, T=T, D=D, Dp=Dp, N=N, dtype=code, table=ptr(table_p), ids=ctx.ids.data_ptr(), ids_stride=stride,
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], w_pack=ptr(w_p), bias=ptr(b_c), x_rows=ptr(ctx.x_rows),
-                          ld_rows=3 * Dp, bwd_ws=ptr(bwd_ws))
+                          ld_rows=3 * Dp)
+        bwd_ws = _ws(_lib.lib().nr_conv_workspace_bytes(C.byref(d)), dev) if ctx.x_rows is not None else None
+        d.bwd_ws, d.bwd_ws_bytes = ptr(bwd_ws), (bwd_ws.numel() * 4 if bwd_ws is not None else 0)
         check(_lib.lib().nr_conv1d_k3_bwd(C.byref(d), ptr(dy), ptr(dwp), ptr(db), _stream()), "nr_conv1d_k3_bwd")
-        dw = torch.empty(N, D, 3, dtype=torch.float32, device=dev)
-        check(_lib.lib().nr_unpack_conv_dw(ptr(dwp), N, D, Dp, ptr(dw), _stream()), "nr_unpack_conv_dw")
+        dw = ctx.targets[0] if direct else torch.empty(N, D, 3, dtype=torch.float32, device=dev)
+        check(_lib.lib().nr_unpack_conv_dw(ptr(dwp), N, D, Dp, ptr(dw), int(direct), _stream()), "nr_unpack_conv_dw")
+        if direct:
+            return None, None, None, None
         return dw, db, None, None
 
 
@@ -376,6 +554,8 @@ def conv1d_k3_gather(table, w, b, ids, T: int, D: int, code: int, p_in=0.0):
     if table.requires_grad:
         raise RuntimeError("NAML title-embedding table must be frozen (freeze_embedding=True, as src/demo.sh:12): "
                            "its [V, T*D] dense gradient is out of scope on this path")
+    if CHECK_INDICES:
+        check_ids(ids, table.shape[0], "news id")
     cfg = dict(code=code, T=T, D=D, p_in=float(p_in), seed_in=draw_seed() if p_in > 0 else 0,
                table_packed=table_cache.get(table, code, row_cols=D))
     return ConvFunction.apply(w, b, ids, cfg)
@@ -397,6 +577,7 @@ class GatherLinearFunction(Function):
                             ids=ids.data_ptr(), ids_stride=stride, w=ptr(w_p), ldw=w_p.shape[1], bias=ptr(b_c), w_t=0, ldwt=0)
         check(_lib.lib().nr_linear_fwd(C.byref(d), ptr(out), N, _stream()), "nr_linear_fwd")
         ctx.code, ctx.dims, ctx.ids = code, (M, K, N, stride, tuple(emb.shape)), ids
+        ctx.targets = tuple(grad_target(p) for p in (emb, w, b)) if torch.is_grad_enabled() else (None,) * 3
         ctx.save_for_backward(emb_p, w_p, b_c, w)
         return out
 
@@ -407,20 +588,29 @@ class GatherLinearFunction(Function):
         code, dev = ctx.code, dout.device
         dout = dout.contiguous().float()
         Nc = round_up(N, chunk(code))
-        ws = torch.empty(M, Nc, dtype=torch_dtype(code), device=dev)
-        dw = torch.zeros(N, K, dtype=torch.float32, device=dev)
-        db = torch.zeros(N, dtype=torch.float32, device=dev)
         need_t = ctx.needs_input_grad[0]
-        dtable = torch.zeros(emb_shape, dtype=torch.float32, device=dev) if need_t else None
+        direct = ctx.targets[1] is not None and ctx.targets[2] is not None and (ctx.targets[0] is not None or not need_t)
+        if direct:
+            dtable, dw, db = (ctx.targets[0] if need_t else None), ctx.targets[1], ctx.targets[2]
+        else:
+            dw = torch.zeros(N, K, dtype=torch.float32, device=dev)
+            db = torch.zeros(N, dtype=torch.float32, device=dev)
+            dtable = torch.zeros(emb_shape, dtype=torch.float32, device=dev) if need_t else None
         w_t = pack(w, code, transpose=True, ld=Nc) if need_t else None               # [K, Nc]
         d = _lib.LinearDesc(M=M, K=K, N=N, dtype=code, src_kind=NR_SRC_GATHER, x=ptr(emb_p), ldx=emb_p.shape[1],
                             ids=ctx.ids.data_ptr(), ids_stride=stride, w=ptr(w_p), ldw=w_p.shape[1], bias=ptr(b_c),
                             w_t=ptr(w_t), ldwt=Nc if need_t else 0)
+        ws = _ws(_lib.lib().nr_linear_workspace_bytes(C.byref(d)), dev)
+        d.dout_ws_bytes = ws.numel() * 4
         check(_lib.lib().nr_linear_bwd(C.byref(d), ptr(dout), N, ptr(ws), ptr(dw), ptr(db), ptr(dtable), _stream()), "nr_linear_bwd")
+        if direct:
+            return None, None, None, None, None
         return dtable, dw, db, None, None
 
 
 def gather_linear(emb, w, b, ids, code: int):
+    if CHECK_INDICES:
+        check_ids(ids, emb.shape[0], "category id")
     return GatherLinearFunction.apply(emb, w, b, ids, code)
 
 
@@ -430,6 +620,8 @@ def embed_gather(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     _need_gpu(table, ids)
     table = table.detach().float().contiguous()
     ids = ids.to(torch.int32).contiguous()
+    if CHECK_INDICES:
+        check_ids(ids, table.shape[0], "news index")
     cols = table.shape[1]
     out = torch.empty(*ids.shape, cols, dtype=torch.float32, device=table.device)
     check(_lib.lib().nr_embed_gather_fwd(ptr(table), cols, NR_F32, ptr(ids), ids.numel(), 1, cols, ptr(out), cols, _stream()),
@@ -442,11 +634,56 @@ def score_eval(news_vecs, cand_ids, imp_of, user_vecs) -> torch.Tensor:
     _need_gpu(news_vecs, cand_ids, imp_of, user_vecs)
     news_vecs, user_vecs = news_vecs.detach().float().contiguous(), user_vecs.detach().float().contiguous()
     cand_ids, imp_of = cand_ids.to(torch.int32).contiguous(), imp_of.to(torch.int32).contiguous()
+    if CHECK_INDICES:
+        check_ids(cand_ids, news_vecs.shape[0], "candidate index")
+        check_ids(imp_of, user_vecs.shape[0], "impression index")
     N = news_vecs.shape[1]
     out = torch.empty(cand_ids.numel(), dtype=torch.float32, device=news_vecs.device)
     check(_lib.lib().nr_score_eval(ptr(news_vecs), N, ptr(cand_ids), ptr(imp_of), ptr(user_vecs), N, ptr(out),
                                    cand_ids.numel(), N, _stream()), "nr_score_eval")
     return out
+
+
+def assemble_batch(news_combined, hist_idx, pos_idx, neg_idx, label):
+    """Row f1: history [B, H, F] = news_combined[hist_idx]; candidate [B, 1+K, F] = news_combined[neg[:label] + [pos] +
+    neg[label:]] (src/dataset.py:40-48 + the DataLoader collate), gathered on the device from int32 index arrays."""
+    _need_gpu(news_combined, hist_idx, pos_idx, neg_idx, label)
+    comb = news_combined if news_combined.dim() == 2 else news_combined.reshape(news_combined.shape[0], -1)
+    if comb.dtype != torch.int32 or not comb.is_contiguous():
+        comb = comb.to(torch.int32).contiguous()
+    hist_idx, pos_idx, neg_idx = (t.to(torch.int32).contiguous() for t in (hist_idx, pos_idx, neg_idx))
+    label = label.to(torch.int64).contiguous()
+    B, H = hist_idx.shape
+    K, F = neg_idx.shape[1], comb.shape[1]
+    dev = comb.device
+    history = torch.empty(B, H, F, dtype=torch.int32, device=dev)
+    candidate = torch.empty(B, 1 + K, F, dtype=torch.int32, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev) if CHECK_INDICES else None
+    check(_lib.lib().nr_assemble_batch(ptr(comb), comb.shape[0], F, ptr(hist_idx), ptr(pos_idx), ptr(neg_idx), ptr(label), B, H, K,
+                                       ptr(history), ptr(candidate), ptr(bad), _stream()), "nr_assemble_batch")
+    if bad is not None and int(bad.item()):
+        raise IndexError(f"assemble_batch: {int(bad.item())} news indices / labels out of range")
+    return history, candidate
+
+
+def eval_metrics(score, label, offsets, max_cand=None, return_per_impression=False):
+    """Row f2: per-impression AUC / MRR / nDCG@5 / nDCG@10 (src/metrics.py, src/main.py:249-263) over CSR candidate lists.
+    Returns a DEVICE fp64 tensor [5] = [scored impressions, sum AUC, sum MRR, sum nDCG@5, sum nDCG@10]
+    (+ the [n_imp, 4] per-impression table, AUC = -1 for skipped impressions, if asked)."""
+    _need_gpu(score, label, offsets)
+    score = score.detach().float().contiguous()
+    label, offsets = label.to(torch.int32).contiguous(), offsets.to(torch.int32).contiguous()
+    n_imp = offsets.numel() - 1
+    if max_cand is None:
+        max_cand = int((offsets[1:] - offsets[:-1]).max().item()) if n_imp > 0 else 0
+    nbytes = int(_lib.lib().nr_eval_metrics_workspace_bytes(n_imp))
+    per_imp = torch.empty(max(nbytes // 8, 4), dtype=torch.float64, device=score.device)
+    sums = torch.empty(5, dtype=torch.float64, device=score.device)
+    check(_lib.lib().nr_eval_metrics(ptr(score), ptr(label), ptr(offsets), n_imp, int(max_cand), ptr(per_imp), per_imp.numel() * 8,
+                                     ptr(sums), _stream()), "nr_eval_metrics")
+    if return_per_impression:
+        return sums, per_imp[: n_imp * 4].view(n_imp, 4)
+    return sums
 
 
 def dropout_mask(count: int, p: float, seed: int, device) -> torch.Tensor:

@@ -1,11 +1,18 @@
-"""Data-parallel plumbing.  One process per GPU; `torch.distributed` backend 'nccl' is RCCL
-on ROCm (xGMI inside a node), 'gloo' on CPU for the host-logic tests.
+"""Data-parallel plumbing of the train / eval loops.  One process per GPU;
+`torch.distributed` backend 'nccl' is RCCL on ROCm (xGMI inside a node), 'gloo' on CPU for the host-logic tests.
 
 The reference wraps the model in DistributedDataParallel (src/main.py:82): rank-0 parameter broadcast at
-construction, gradient all-reduce-mean in backward.  `wrap_ddp` does exactly that; `FlatBucketDP` is the
-single-collective alternative: all gradients live in ONE contiguous fp32 bucket (4 MB for NRMS, + the table
-gradient when it is trainable) and are averaged with one all_reduce per step — on a fully connected 8-GPU xGMI
-mesh that message is latency bound, so one launch beats DDP's several buckets.
+construction, gradient all-reduce-mean in backward, then `optim.Adam.step()` (src/main.py:76,110).  Two modes here,
+chosen by `args.dp_mode` in `train.train()`:
+
+  "flat" (default on the GPU)  `FlatBucket`: every trainable parameter lives in ONE contiguous fp32 buffer, every
+        gradient in another, Adam's moments in two more.  The autograd functions of `ops.py` accumulate straight
+        into the gradient buffer, `step()` is ONE all-reduce over it (4 MB for NRMS + the word-table gradient when
+        it is trainable -- latency bound on the xGMI mesh, so one message beats DDP's several buckets) and ONE HIP
+        kernel (`nr_adam_step`) that applies the 1/world average, Adam's update and the next step's zero_grad.
+  "ddp"   the reference's own objects: `DistributedDataParallel` + `torch.optim.Adam` (fused on the GPU).
+
+Both have the reference's semantics (same broadcast, same mean, same update rule).
 """
 import os
 
@@ -13,66 +20,158 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
-    """Process-group init from the torchrun environment; returns (rank, local_rank, world)."""
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+def init_distributed(rank=None, world=None, backend=None, device=None):
+    """Process-group init, `env://` as src/main.py:31,154.  rank / world default to the torchrun environment
+    (RANK / WORLD_SIZE); MASTER_ADDR / MASTER_PORT default to 127.0.0.1:8888 (src/main.py:286-287 uses localhost:8888).
+    Returns (rank, world).  world == 1: no process group is created."""
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+    rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
     if world > 1 and not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "8888")
+        if backend is None:
+            backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
         kw = {}
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            kw["device_id"] = torch.device("cuda", local_rank)
-        dist.init_process_group(backend, **kw)
-    return rank, local_rank, world
+            kw["device_id"] = torch.device(device)
+        dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank, **kw)
+    return rank, world
 
 
-def wrap_ddp(model, local_rank):
+def world_size(group=None):
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def agree_on_batches(n_local_batches, device, group=None):
+    """Number of batches EVERY rank can run.  Shards written round-robin (`i % nGPU`, src/prepare_data.py:39-41) differ by
+    up to one sample, so ranks can disagree on the batch count and the extra gradient all-reduce of the longer ranks
+    never completes (the reference's latent hang).  One MIN all-reduce before the epoch fixes the count."""
+    if world_size(group) == 1:
+        return int(n_local_batches)
+    t = torch.tensor([int(n_local_batches)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
+
+
+def wrap_ddp(model, device):
     """Same wrapper and defaults as src/main.py:82."""
-    ids = [local_rank] if next(model.parameters()).is_cuda else None
+    ids = [torch.device(device).index] if torch.device(device).type == "cuda" else None
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids)
 
 
-class FlatBucketDP:
-    """Gradient averaging through one flat bucket.
+def reduce_eval_sums(n_samples, n_scored, metric_sums, device, group=None):
+    """src/main.py:269-273: SUM-reduce of the sample count and the four metric sums to rank 0, as ONE message
+    [n_samples, n_scored, sum AUC, sum MRR, sum nDCG@5, sum nDCG@10] (fp64).  Every rank gets the tuple back; only
+    rank 0's is the global one."""
+    t = torch.tensor([float(n_samples), float(n_scored), *[float(x) for x in metric_sums]], dtype=torch.float64, device=device)
+    if world_size(group) > 1:
+        dist.reduce(t, dst=0, op=dist.ReduceOp.SUM, group=group)
+    v = t.cpu().tolist()
+    return int(round(v[0])), int(round(v[1])), v[2:]
 
-        dp = FlatBucketDP(model)         # broadcasts rank 0's parameters (DDP construction semantics)
-        loss.backward(); dp.allreduce_grads(); optimizer.step()
-    """
 
-    def __init__(self, model, group=None, broadcast=True):
-        self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.params = [p for p in model.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.bucket = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
-        for p in self.params:                      # grads become views of the bucket: no per-step flatten copy
-            p.grad = self.bucket[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        if broadcast and self.world > 1:
-            flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
-            dist.broadcast(flat, src=0, group=group)
-            off = 0
-            for p in model.parameters():
-                p.data.copy_(flat[off:off + p.numel()].view_as(p))
+def _align(n, a=64):
+    return (n + a - 1) // a * a
+
+
+class FlatBucket:
+    """Parameters, gradients and Adam state of `model` as four flat fp32 buffers.
+
+        fb = FlatBucket(model, lr=args.lr)      # model already on its device; broadcasts rank 0's parameters
+        loss.backward()                         # ops.py accumulates into fb.grad directly
+        fb.step()                               # all-reduce (world > 1) + fused Adam + zero_grad, two launches
+
+    Layout: the three projections of every MultiHeadSelfAttention are adjacent (weights [3N, d_model], then biases [3N])
+    so the QKV GEMMs read / write them without a concatenation; every other parameter starts on a 256-byte boundary.
+    Frozen parameters stay where they are."""
+
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, group=None, broadcast=True):
+        from .model.model_utils import MultiHeadSelfAttention
+        self.group, self.world = group, world_size(group)
+        self.lr, self.betas, self.eps, self.t = float(lr), (float(betas[0]), float(betas[1])), float(eps), 0
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("FlatBucket: the model has no trainable parameter")
+        dev = params[0].device
+        if any(p.device != dev or p.dtype != torch.float32 for p in params):
+            raise ValueError("FlatBucket: trainable parameters must be fp32 on one device")
+        # segments: parameters laid out back to back, each segment starting on a 256-byte boundary
+        segments, seen, groups = [], set(), []
+        for m in model.modules():
+            if isinstance(m, MultiHeadSelfAttention):
+                ws, bs = [m.W_Q.weight, m.W_K.weight, m.W_V.weight], [m.W_Q.bias, m.W_K.bias, m.W_V.bias]
+                if all(p.requires_grad and id(p) not in seen for p in ws + bs):
+                    groups.append((m, len(segments)))        # weights segment, then biases segment
+                    segments += [ws, bs]
+                    seen.update(id(p) for p in ws + bs)
+        segments += [[p] for p in params if id(p) not in seen]
+        order, offs, seg_off, off = [], [], [], 0
+        for seg in segments:
+            off = _align(off)
+            seg_off.append(off)
+            for p in seg:
+                order.append(p)
+                offs.append(off)
                 off += p.numel()
+        self.numel = _align(off)
+        self.param = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.param)
+        self.exp_avg = torch.zeros_like(self.param)
+        self.exp_avg_sq = torch.zeros_like(self.param)
+        self.params, self.views = order, []
+        with torch.no_grad():
+            for p, o in zip(order, offs):
+                pv, gv = self.param[o:o + p.numel()].view_as(p), self.grad[o:o + p.numel()].view_as(p)
+                pv.copy_(p)
+                p.data = pv                          # the Parameter object (and its state_dict key) stays, its storage moves
+                p.grad = gv
+                p._nr_grad = gv
+                self.views.append((pv, gv))
+        for m, si in groups:
+            N, d_model = segments[si][0].shape
+            o_w, o_b = seg_off[si], seg_off[si + 1]
+            m._nr_flat = {"w": self.param[o_w:o_w + 3 * N * d_model].view(3 * N, d_model), "b": self.param[o_b:o_b + 3 * N],
+                          "gw": self.grad[o_w:o_w + 3 * N * d_model].view(3 * N, d_model), "gb": self.grad[o_b:o_b + 3 * N]}
+        self._model = model
+        if broadcast and self.world > 1:             # DDP construction semantics (src/main.py:82): rank 0's parameters win
+            dist.broadcast(self.param, src=0, group=group)
+        self._params_changed()
+
+    def _params_changed(self):
+        from . import ops
+        ops.table_cache.invalidate()                 # packed bf16 copies of embedding tables follow the fp32 master
 
     def zero_grad(self):
-        self.bucket.zero_()
+        self.grad.zero_()
 
-    def allreduce_grads(self):
-        off = 0
-        for p in self.params:                      # autograd may have replaced .grad: fold it back into the bucket
-            view = self.bucket[off:off + p.numel()].view_as(p)
-            if p.grad is None:
-                view.zero_()
-            elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-            p.grad = view
-            off += p.numel()
+    def allreduce(self):
+        """The one collective of a step: SUM over ranks (the 1/world of the mean is applied inside the Adam kernel)."""
         if self.world > 1:
-            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
-            self.bucket.div_(self.world)
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+
+    def adam_step(self, zero_grad=True):
+        if not self.param.is_cuda:
+            raise RuntimeError("FlatBucket.adam_step runs the HIP kernel nr_adam_step: parameters must live on the GPU "
+                               "(libnrhip has no CPU fallback)")
+        from . import _lib
+        self.t += 1
+        _lib.check(_lib.lib().nr_adam_step(self.param.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                           self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps,
+                                           self.t, 1.0 / self.world, int(zero_grad), torch.cuda.current_stream().cuda_stream),
+                   "nr_adam_step")
+        self._params_changed()
+
+    def step(self):
+        self.allreduce()
+        self.adam_step(zero_grad=True)
+
+    # -- checkpoint interop: torch.optim.Adam's state_dict layout (per-parameter exp_avg / exp_avg_sq / step)
+    def state_dict(self):
+        names = {id(p): n for n, p in self._model.named_parameters()}
+        st = {}
+        for p, (pv, gv) in zip(self.params, self.views):
+            o = pv.data_ptr() - self.param.data_ptr()
+            o //= 4
+            st[names[id(p)]] = {"step": self.t, "exp_avg": self.exp_avg[o:o + p.numel()].view_as(p).clone(),
+                                "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view_as(p).clone()}
+        return {"state": st, "lr": self.lr, "betas": self.betas, "eps": self.eps}

@@ -69,3 +69,54 @@ def test_package_metrics_match_reference_fixture(golden_dir):
         y, s = np.array(r["y"]), np.array(r["s"], dtype=np.float32)
         got = [M.roc_auc_score(y, s), M.mrr_score(y, s), M.ndcg_score(y, s, 5), M.ndcg_score(y, s, 10)]
         assert np.allclose(got, r["auc_mrr_ndcg5_ndcg10"], atol=1e-12)
+
+
+def test_title_embedding_file_round_trip_and_mmap_cache(tmp_path):
+    """Row f3: `title_embeddings.*.npy.gz` as src/preprocess.py:154-158 writes it (np.save through gzip), read back the
+    reference's way and through the inflate-once + memory-map path: identical arrays; the cache is reused."""
+    import gzip
+    from newsrecommendation_amd import formats as F
+    rnd = np.random.RandomState(0)
+    emb = rnd.randn(37, 4, 6).astype(np.float32)                   # [N+1, T, D] -> flattened [N+1, T*D]
+    d = str(tmp_path)
+    path = F.write_news_embeddings(d, emb, "bpemb")
+    with gzip.GzipFile(path, "r") as f:                            # exactly src/preprocess.py:229-231
+        ref = np.load(f)
+    assert ref.shape == (37, 24) and np.array_equal(ref, emb.reshape(37, -1))
+    a = F.read_news_embeddings(d, "bpemb", mmap=False)
+    b = F.read_news_embeddings(d, "bpemb")
+    assert isinstance(b, np.memmap) and np.array_equal(a, ref) and np.array_equal(np.asarray(b), ref)
+    npy = path[:-3]
+    t0 = os.path.getmtime(npy)
+    c = F.read_news_embeddings(d, "bpemb")
+    assert os.path.getmtime(npy) == t0 and np.array_equal(np.asarray(c), ref)       # not inflated again
+    shape, dtype, off = F.npy_header(npy)
+    assert shape == (37, 24) and dtype == np.float32 and off % 64 == 0
+    got = np.concatenate([blk for _, blk in F.rows_in_blocks(b, rows_per_block=10)])
+    assert np.array_equal(got, ref)
+    F.write_news_embeddings(d, emb[:5], "bert")
+    assert F.read_news_embeddings(d, "bert").shape == (5, 24)
+
+
+def test_indexed_shards_equal_the_line_by_line_datasets(golden_dir, tmp_path):
+    """IndexedTrainShard / IndexedTestShard (parse once) against the reference-recorded per-line streams."""
+    g = _golden(golden_dir)
+    args = argparse.Namespace(user_log_length=g["user_log_length"], npratio=g["npratio"])
+    for n_shards, case in g["cases"].items():
+        for r in range(int(n_shards)):
+            f = tmp_path / f"tr_{n_shards}_{r}.tsv"
+            f.write_text("".join(case["train_shards"][r]))
+            sh = D.IndexedTrainShard(str(f), g["news_index"], args)
+            random.seed(g["seed"] + r)
+            lab = sh.draw_labels()
+            for i, (hist, mask, sample, label) in enumerate(case["train_stream"][r]):
+                assert sh.hist[i].tolist() == hist and sh.mask[i].tolist() == mask and int(lab[i]) == label
+                neg = sh.neg[i].tolist()
+                assert neg[:label] + [int(sh.pos[i])] + neg[label:] == sample
+            f = tmp_path / f"te_{n_shards}_{r}.tsv"
+            f.write_text("".join(case["test_shards"][r]))
+            st = D.IndexedTestShard(str(f), g["news_index"], args)
+            for i, (hist, mask, cand, labels) in enumerate(case["test_stream"][r]):
+                a, b = st.offsets[i], st.offsets[i + 1]
+                assert st.hist[i].tolist() == hist and st.mask[i].tolist() == mask
+                assert st.cand[a:b].tolist() == cand and st.label[a:b].tolist() == labels

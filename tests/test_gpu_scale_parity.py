@@ -1,0 +1,162 @@
+"""GPU: oracle parity at PRODUCTION scale -- the kernels that make up the benchmarked step.
+
+The live-row / live-slab / sequence-list paths of libnrhip are size gated (M % 32 == 0 and M >= 200 000 token rows):
+the golden cases (M <= 6 600) never reach them.  B = 128 gives M = 128 * 55 * 30 = 211 200 rows, which does, on a
+MIND-shaped batch (bench.synth_batches: title tails zero padded, empty history slots, front-padded histories), and the
+CPU oracle still finishes it in seconds.  Every case compares loss, score and EVERY parameter gradient at full resolution
+with oracle.nrms_forward / naml_forward, asserts through the library's own launch log that the size-gated kernels
+really ran, and pre-fills the buffers those kernels leave partly unwritten (qkv / dqkv rows of all-padding sequences)
+with NaN so that a read of an unwritten row cannot pass silently.
+
+Tolerances (measured on MI355X, then fixed here):
+  fp32 compute: loss / score 1e-4 abs (north_star), gradients 2e-4 * max|g| + 1e-6.
+  bf16 compute: loss / score 3e-2 abs; gradients 3e-2 * max|g| + 3e-4 -- the absolute floor covers d W_K.bias, which is
+  analytically ~0 (a constant key shift leaves the softmax unchanged) so only bf16 rounding noise of dK remains.
+"""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+import bench
+from helpers import assert_close
+from newsrecommendation_amd import _lib, ops
+from oracle import nr_oracle as O
+
+pytestmark = pytest.mark.gpu
+B = 128
+
+
+def _launched():
+    return set(_lib.prof_collect().keys())
+
+
+def _has(labels, prefix):
+    return any(l.startswith(prefix) for l in labels)
+
+
+def _grad_report(model, oracle_grads, atol, rtol):
+    worst = {}
+    for name, p in model.named_parameters():
+        if not p.requires_grad or name not in oracle_grads:
+            continue
+        assert p.grad is not None, name
+        assert torch.isfinite(p.grad).all(), f"non-finite gradient in {name} (an unwritten workspace row was read?)"
+        ref = oracle_grads[name]
+        err = float((p.grad.detach().double().cpu() - ref.double()).abs().max())
+        worst[name] = err / (float(ref.abs().max()) + 1e-30)
+        assert_close(p.grad, ref, atol, rtol, name="d" + name)
+    return worst
+
+
+def _nrms_case(dt, seed):
+    cfg = O.default_cfg()
+    g = torch.Generator().manual_seed(seed)
+    V = 5000
+    table = torch.randn(V, cfg.word_embedding_dim, generator=g) * 0.4
+    table[0] = 0
+    sd = O.init_state_dict("NRMS", cfg, table, seed=seed + 1)
+    from newsrecommendation_amd.model import NRMS
+    args = SimpleNamespace(**vars(cfg), compute_dtype=dt)
+    m = NRMS.Model(args, table.numpy())
+    m.load_state_dict(sd, strict=True)
+    hist, mask, cand, label = bench.synth_batches(cfg, B, V, 1, seed + 2, "cpu")[0]
+    # the shape the gates need, and the padding structure the skips act on
+    assert (B * 55 * 30) % 32 == 0 and B * 55 * 30 >= 200000
+    assert int((hist == 0).all(-1).sum()) > B and float((hist == 0).float().mean()) > 0.5 and int((mask.sum(1) == 0).sum()) >= 1
+    cand[0, 1] = 0                                     # an all-padding CANDIDATE title (unknown news -> index 0, dataset.py:15)
+    return cfg, sd, m.cuda(), (hist, mask, cand, label)
+
+
+TOL = {"fp32": dict(tol=1e-4, gatol=1e-6, grtol=2e-4), "bf16": dict(tol=3e-2, gatol=3e-4, grtol=3e-2)}
+
+
+@pytest.mark.parametrize("dt,train", [("bf16", False), ("bf16", True), ("fp32", False)])
+def test_nrms_b128_every_gradient_against_the_oracle(dt, train):
+    cfg, sd, m, (hist, mask, cand, label) = _nrms_case(dt, 40)
+    t = TOL[dt]
+    m.train(train)
+    keep = None
+    ops.POISON_WORKSPACES = True
+    _lib.prof_enable(1)
+    try:
+        _lib.prof_collect()
+        if train:
+            torch.manual_seed(4321)
+            seed_in, seed_out = ops.draw_seed(), ops.draw_seed()        # the two draws NewsEncoder.forward makes
+            torch.manual_seed(4321)
+        loss, score = m(hist.cuda(), mask.cuda(), cand.cuda(), label.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        labels = _launched()
+    finally:
+        _lib.prof_enable(0)
+        ops.POISON_WORKSPACES = False
+    if dt == "bf16":
+        # the kernels of the benchmarked step, not their small-shape stand-ins
+        for want in ("gemm_tn3_live", "attn_mfma_bwd_live", "gemm_nt_dma_live", "attn_mfma_fwd", "pool_core_bwd"):
+            assert _has(labels, want), (want, sorted(labels))
+    if train:
+        n, T, D, N, p = B * 55, cfg.num_words_title, cfg.word_embedding_dim, cfg.news_dim, cfg.drop_rate
+        word = ops.dropout_mask(n * T * D, p, seed_in, "cuda").cpu().reshape(n, T, D)
+        ctx = ops.dropout_mask(n * T * N, p, seed_out, "cuda").cpu().reshape(n, T, N)
+        nc = B * 5
+        keep = {"cand_word": word[:nc], "hist_word": word[nc:], "cand_ctx": ctx[:nc], "hist_ctx": ctx[nc:]}
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    lo, so = O.nrms_forward(hist, mask, cand, label, sdo, cfg, keep=keep)
+    lo.backward()
+    assert torch.isfinite(score).all() and torch.isfinite(loss)
+    assert_close(loss, lo.detach(), t["tol"], name="loss")
+    assert_close(score, so.detach(), t["tol"], name="score")
+    worst = _grad_report(m, {k: v.grad for k, v in sdo.items() if v.grad is not None}, t["gatol"], t["grtol"])
+    print(f"nrms B={B} {dt} train={train}: loss {float(loss):.6f} vs {float(lo):.6f}; worst grad err / max|g|: "
+          + ", ".join(f"{k.split('.', 1)[1]}={v:.2e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]))
+    tab = dict(m.named_parameters())["news_encoder.embedding_matrix.weight"]
+    assert float(tab.grad[0].abs().max()) == 0.0                          # padding_idx row
+
+
+@pytest.mark.parametrize("dt,train", [("bf16", True), ("fp32", False)])
+def test_naml_b128_every_gradient_against_the_oracle(dt, train):
+    cfg = O.default_cfg(use_category=True, use_subcategory=True, freeze_embedding=True)
+    g = torch.Generator().manual_seed(50)
+    n_news = 2500
+    T, D = cfg.num_words_title, cfg.word_embedding_dim
+    table = torch.randn(n_news + 1, T * D, generator=g) * 0.4
+    table[0] = 0
+    sd = O.init_state_dict("NAML", cfg, table, seed=51, n_cat=17, n_sub=264)
+    from newsrecommendation_amd.model import NAML
+    args = SimpleNamespace(**vars(cfg), compute_dtype=dt)
+    m = NAML.Model(args, table.numpy(), 17, 264)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train(train)
+    hist, mask, cand, label = bench.synth_batches_naml(cfg, B, n_news, 1, 52, "cpu")[0]
+    assert int((mask == 0).sum()) > B                                     # masked history slots: zero upstream gradient
+    t = TOL[dt]
+    _lib.prof_enable(1)
+    try:
+        _lib.prof_collect()
+        if train:
+            torch.manual_seed(99)
+            seed_in = ops.draw_seed()
+            torch.manual_seed(99)
+        loss, score = m(hist.cuda(), mask.cuda(), cand.cuda(), label.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        labels = _launched()
+    finally:
+        _lib.prof_enable(0)
+    if dt == "bf16":
+        assert _has(labels, "gemm_tn3_live"), sorted(labels)                # conv dW over the live slabs
+    keep = None
+    if train:
+        n = B * 55
+        word = ops.dropout_mask(n * T * D, cfg.drop_rate, seed_in, "cuda").cpu().reshape(n, T, D)
+        keep = {"cand_word": word[: B * 5], "hist_word": word[B * 5:]}
+    sdo = {k: v.clone().requires_grad_(k != "news_encoder.title_embeddings.weight") for k, v in sd.items()}
+    lo, so = O.naml_forward(hist, mask, cand, label, sdo, cfg, keep=keep)
+    lo.backward()
+    assert_close(loss, lo.detach(), t["tol"], name="loss")
+    assert_close(score, so.detach(), t["tol"], name="score")
+    worst = _grad_report(m, {k: v.grad for k, v in sdo.items() if v.grad is not None}, t["gatol"], t["grtol"])
+    print(f"naml B={B} {dt} train={train}: worst grad err / max|g|: "
+          + ", ".join(f"{k.split('.', 1)[1]}={v:.2e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]))

@@ -45,8 +45,13 @@ def _synth(tmp, n_news=120, vocab=300, n_imp=1000, seed=5):
     return args, news_index, news_combined.numpy(), table.numpy()
 
 
-def test_train_loop_tracks_oracle_and_eval_matches(tmp_path):
+@pytest.mark.parametrize("dp_mode,feed", [("flat", "device"), ("ddp", "host")])
+def test_train_loop_tracks_oracle_and_eval_matches(tmp_path, dp_mode, feed):
+    """("flat", "device") = the product defaults: batches assembled on the device from index arrays (row f1), gradients
+    accumulated straight into the flat bucket, HIP fused Adam (row f4), device-side ranking metrics (row f2).
+    ("ddp", "host") = the reference's own objects (DataLoader, torch.optim.Adam)."""
     args, news_index, news_combined, table = _synth(str(tmp_path))
+    args.dp_mode, args.feed = dp_mode, feed
     n = D.prepare_training_data(args.train_data_dir, 1, args.npratio, seed=0)
     assert n > 100
     steps = 15
@@ -71,7 +76,7 @@ def test_train_loop_tracks_oracle_and_eval_matches(tmp_path):
         loss.backward()
         opt.step()
         ref.append(float(loss))
-    assert max(abs(a - b) for a, b in zip(losses, ref)) < 2e-3, (losses, ref)
+    assert max(abs(float(a) - b) for a, b in zip(losses, ref)) < 2e-3, (losses, ref)
     assert losses[-1] < losses[0]
 
     # eval loop vs the oracle's per-impression path on the trained weights
