@@ -5,18 +5,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one full training step of the reference loop (src/main.py:98-110) on one resident
-synthetic MIND-shaped batch: forward (dropout 0.2 on, as `model.train()`), loss, backward (incl. the
-word-embedding table gradient: `freeze_embedding` defaults to False, src/parameters.py:47), gradient
-all-reduce when N > 1 (DistributedDataParallel over RCCL, as src/main.py:82), Adam step.
+One "step" = one full training step of the reference loop (src/main.py:98-110) on one resident synthetic MIND-shaped
+batch: forward (dropout 0.2 on, as `model.train()`), loss, backward (incl. the word-embedding table gradient:
+`freeze_embedding` defaults to False, src/parameters.py:47), gradient all-reduce-mean when N > 1, Adam step.
 Weak scaling: every rank owns its own 512-impression shard per step (impressions are independent).
 
+Other workloads the same script measures (each prints ONE JSON line of the same shape):
+    --dtype fp32          the exact-fp32 mode that is held to 1e-4 against the CPU oracle
+    --model NAML          BASELINE configs[2] (3 views, frozen [N+1, T*D] title table)
+    --dense-batch         full histories and full-length titles (no padding for the sparsity shortcuts to use)
+    --feed device         batches assembled on the device from news-index arrays every step
+    --dp-mode ddp         DistributedDataParallel + torch.optim.Adam (the reference's objects) instead of the flat bucket
+    --eval                BASELINE configs[4] per GPU: encode --eval-news news once, score --eval-impressions impressions,
+                          ranking metrics on the device (a "step" is one pass over the impression shard)
+
 The JSON line also carries
-  roofline     - the dominant libnrhip kernel of the timed region, timed live with HIP events inside the
-                 library (nr_prof_*), against the MI355X dense-MFMA / HBM peak;
+  roofline     - the dominant libnrhip kernel of the timed region, timed live with HIP events inside the library
+                 (nr_prof_*), against the MI355X dense-MFMA / HBM peak; "step": the whole step against the binding (MFMA)
+                 bound and its HBM bytes (PMC file) against the fused-minimum bytes of SURVEY §8(d);
   cpu_baseline - the CPU oracle (a port, torch-CPU fp32) timed on this host on a bounded sample.
 """
 import argparse
+import glob
 import json
 import os
 import re
@@ -33,6 +43,10 @@ PEAK_MFMA_BF16 = 2500.0   # TFLOP/s dense (MI355X_MICROARCH.md, Chip-level param
 PEAK_MFMA_F32 = 157.3
 PEAK_HBM = 8000.0         # GB/s
 
+# algorithmic forward FLOPs per impression (55 titles + user encoder + scorer) and the fused-minimum bytes
+FWD_GFLOP_PER_IMP = {"NRMS": 1.593, "NAML": 1.497}
+FUSED_MIN_BYTES_PER_IMP_FWD = {"bf16": 1.085e6, "fp32": 2.075e6}
+
 
 def make_args(dtype):
     return SimpleNamespace(num_words_title=30, user_log_length=50, npratio=4, word_embedding_dim=300, news_dim=400,
@@ -41,27 +55,30 @@ def make_args(dtype):
                            category_emb_dim=100, compute_dtype=dtype)
 
 
-def synth_batches(args, B, V, n_batches, seed, device):
+def synth_batches(args, B, V, n_batches, seed, device, dense=False):
     """Seeded MIND-shaped batches: title length ~U[5,30] zero padded, history length ~U[0,50]
-    front padded, 1+K candidates, label ~U[0,K]."""
+    front padded, 1+K candidates, label ~U[0,K].  dense: every title 30 tokens, every history 50 clicks."""
     g = torch.Generator().manual_seed(seed)
     T, H, C = args.num_words_title, args.user_log_length, 1 + args.npratio
     out = []
     for _ in range(n_batches):
         hist = torch.randint(1, V, (B, H, T), generator=g, dtype=torch.int32)
         cand = torch.randint(1, V, (B, C, T), generator=g, dtype=torch.int32)
-        for t in (hist, cand):
-            ln = torch.randint(5, T + 1, t.shape[:2], generator=g)
-            t[torch.arange(T)[None, None, :] >= ln[..., None]] = 0
-        hl = torch.randint(0, H + 1, (B,), generator=g)
-        mask = (torch.arange(H)[None, :] >= (H - hl)[:, None]).float()
-        hist[mask == 0] = 0
+        if dense:
+            mask = torch.ones(B, H)
+        else:
+            for t in (hist, cand):
+                ln = torch.randint(5, T + 1, t.shape[:2], generator=g)
+                t[torch.arange(T)[None, None, :] >= ln[..., None]] = 0
+            hl = torch.randint(0, H + 1, (B,), generator=g)
+            mask = (torch.arange(H)[None, :] >= (H - hl)[:, None]).float()
+            hist[mask == 0] = 0
         label = torch.randint(0, C, (B,), generator=g, dtype=torch.int64)
         out.append(tuple(x.to(device) for x in (hist, mask, cand, label)))
     return out
 
 
-def synth_batches_naml(args, B, n_news, n_batches, seed, device):
+def synth_batches_naml(args, B, n_news, n_batches, seed, device, dense=False):
     """NAML inputs: [news id, category id (<=17), subcategory id (<=264)] per slot."""
     g = torch.Generator().manual_seed(seed)
     H, C = args.user_log_length, 1 + args.npratio
@@ -72,7 +89,7 @@ def synth_batches_naml(args, B, n_news, n_batches, seed, device):
                                 torch.randint(0, 18, shape, generator=g, dtype=torch.int32),
                                 torch.randint(0, 265, shape, generator=g, dtype=torch.int32)], dim=-1)
         hist, cand = ids((B, H)), ids((B, C))
-        hl = torch.randint(0, H + 1, (B,), generator=g)
+        hl = torch.full((B,), H) if dense else torch.randint(0, H + 1, (B,), generator=g)
         mask = (torch.arange(H)[None, :] >= (H - hl)[:, None]).float()
         hist[mask == 0] = 0
         label = torch.randint(0, C, (B,), generator=g, dtype=torch.int64)
@@ -80,117 +97,334 @@ def synth_batches_naml(args, B, n_news, n_batches, seed, device):
     return out
 
 
-def gemm_flops(label):
-    m = re.search(r"M=(\d+),N=(\d+),K=(\d+)", label)
-    M, N, K = (int(x) for x in m.groups())
-    return 2.0 * M * N * K
+def synth_news_table(args, n_news, V, seed):
+    """news_combined [n_news+1, T] int32: title token ids, length ~U[5,30], zero padded; row 0 = the unknown news."""
+    g = torch.Generator().manual_seed(seed)
+    T = args.num_words_title
+    comb = torch.randint(1, V, (n_news + 1, T), generator=g, dtype=torch.int32)
+    ln = torch.randint(5, T + 1, (n_news + 1,), generator=g)
+    comb[torch.arange(T)[None, :] >= ln[:, None]] = 0
+    comb[0] = 0
+    return comb
 
 
-def attn_bytes(label, esz):
-    m = re.search(r"n=(\d+),L=(\d+),h=(\d+),d=(\d+)", label)
-    n, L, h, d = (int(x) for x in m.groups())
-    rows, N = n * L, h * d
-    if "_fwd" in label.split("[")[0]:
-        return rows * (3 * N + N) * esz            # read Q|K|V, write y
-    return rows * (3 * N + N + 3 * N) * esz        # read Q|K|V + dy, write dQ|dK|dV
+# ----------------------------------------------------------------------------------------- pricing
+def batch_structure(batches, args, model_name):
+    """What the device-side compactions of libnrhip see in these batches, recomputed on the host outside the timed region:
+    share of token rows with a non-padding id (`*_live` NT GEMMs), share of 32-row slabs that touch a title with a
+    non-zero upstream gradient (`gemm_tn3_live`), share of sequences the attention backward walks."""
+    T = args.num_words_title
+    live_rows, live_slabs, live_seq, n = [], [], [], 0
+    for hist, mask, cand, _ in batches:
+        B, H = mask.shape
+        C = cand.shape[1]
+        nz_title = torch.cat([torch.ones(B * C, device=mask.device), (mask.reshape(-1) != 0).float()])          # dy != 0
+        if model_name == "NRMS":
+            ids = torch.cat([cand.reshape(B * C, T), hist.reshape(B * H, T)])
+            live_rows.append(float((ids != 0).float().mean()))
+            allpad = (ids == 0).all(-1)
+        else:
+            live_rows.append(1.0)
+            allpad = torch.zeros_like(nz_title, dtype=torch.bool)
+        M = nz_title.numel() * T
+        row_nz = nz_title.repeat_interleave(T)
+        pad = (-M) % 32
+        slab_nz = torch.nn.functional.pad(row_nz, (0, pad)).view(-1, 32).amax(1)
+        live_slabs.append(float(slab_nz.mean()))
+        near = torch.nn.functional.max_pool1d(nz_title[None, None], kernel_size=7, stride=1, padding=3)[0, 0] > 0
+        live_seq.append(float((~(allpad & ~near)).float().mean()))
+    avg = lambda x: sum(x) / len(x)
+    return {"live_token_rows": round(avg(live_rows), 4), "live_gradient_slabs": round(avg(live_slabs), 4),
+            "attention_bwd_sequences": round(avg(live_seq), 4)}
+
+
+def _dims(label, pat):
+    m = re.search(pat, label)
+    return tuple(int(x) for x in m.groups()) if m else None
+
+
+def price_kernel(label, avg_ms, struct, dtype):
+    """(bound, achieved, peak, unit, algorithmic work) of one kernel label.  GEMMs: 2*M*N*K over the rows they really
+    contract (device-side live counts, see batch_structure); attention / pooling / row kernels: algorithmic bytes."""
+    esz = 2 if "bf16" in label or dtype == "bf16" else 4
+    s = avg_ms / 1e3
+    name = label.split("[")[0]
+    if name.startswith("gemm"):
+        d = _dims(label, r"M(?:max)?=(\d+),N=(\d+),K=(\d+)")
+        if d is None:
+            return None
+        M, N, K = d
+        if name.endswith("_live"):
+            M = M * (struct["live_gradient_slabs"] if name.startswith("gemm_tn") else struct["live_token_rows"])
+        fl = 2.0 * M * N * K
+        peak = PEAK_MFMA_BF16 if "bf16" in label else PEAK_MFMA_F32
+        return {"bound": "mfma", "achieved": round(fl / s / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "work": fl}
+    if name.startswith("attn") or name.startswith("mhsa_fused"):
+        d = _dims(label, r"n=(\d+),L=(\d+),h=(\d+),d=(\d+)")
+        n, L, h, dd = d
+        rows, N = n * L, h * dd
+        if name.startswith("mhsa_fused_bwd"):
+            by = rows * (304 + N + N) * esz                      # read x rows + y-gradient, write packed dQ|dK|dV-free outputs
+        elif name.startswith("mhsa_fused"):
+            by = rows * (304 + N) * esz
+        elif "fwd" in name:
+            by = rows * (3 * N + N) * esz                        # read Q|K|V, write y
+        else:
+            by = rows * (3 * N + N + 3 * N) * esz                # read Q|K|V + dy, write dQ|dK|dV
+            if name.endswith("_live"):
+                by *= struct["attention_bwd_sequences"]
+        return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}
+    if name.startswith("pool_core"):
+        n, L, N, q = _dims(label, r"n=(\d+),L=(\d+),N=(\d+),q=(\d+)")
+        by = n * L * (N + q) * esz * (1 if "fwd" in name else 1) + n * L * q * esz * (0 if "fwd" in name else 1)
+        return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}
+    if name.startswith("rows_materialize"):
+        M, K = _dims(label, r"M=(\d+),K=(\d+)")
+        by = M * K * esz
+        return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}
+    return None
+
+
+def pmc_file():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")))
+    return json.load(open(files[-1])) if files else None
 
 
 def pmc_traffic(label):
     """HBM bytes per launch of the kernel behind `label`, from the committed rocprofv3 PMC passes of this command
     (profiles/*_hbm_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled as
     MI355X_MICROARCH.md prescribes for 16-byte coalesced reads on gfx950).  None when no matching entry exists."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")))
-    if not files:
+    pm = pmc_file()
+    if pm is None:
         return None
     key = {"gemm_nt[": "gemm_nt_kernelIDF16bLi0ELi0", "gemm_nt_dma": "gemm_nt_dma_kernel", "gemm_tn2": "tn2::gemm_tn2_kernel", "gemm_tn3": "tn3::gemm_tn3_kernel",
-           "attn_mfma_bwd": "b16::bwd_kernel", "attn_mfma_fwd": "b16::fwd_kernel", "gemm_nt_wide": "gemm_nt_wide_kernel"}
+           "attn_mfma_bwd": "b16::bwd_kernel", "attn_mfma_fwd": "b16::fwd_kernel", "gemm_nt_wide": "gemm_nt_wide_kernel",
+           "mhsa_fused_fwd": "fused_fwd", "mhsa_fused_bwd": "fused_bwd"}
     want = next((v for k, v in key.items() if label.startswith(k)), None)
     if want is None:
         return None
     if label.startswith("gemm_nt_dma") and "epi=" in label:      # one instantiation per epilogue: <EPI, NT16, PK>
         want += "<" + label.split("epi=")[1].split(",")[0] + ","
-    for k in json.load(open(files[-1]))["kernels"]:
+    for k in pm["kernels"]:
         if want in k["kernel"]:
             return round((k["fetch_GB_x2_gfx950_16B_correction"] + k["write_GB"]) * 1e9)
     return None
 
 
-def live_sequence_fraction(batches, args):
-    """Share of the B*(1+K+H) title sequences the attention backward really processes (label "attn_mfma_bwd_live"): it leaves
-    out the all-padding sequences whose own and 3 neighbours' upstream gradients are exactly zero (masked history slots far
-    from any live title) -- nothing downstream reads their dQ|dK|dV rows.  Recomputed here from the batch tensors, outside the
-    timed region, to price that kernel with the bytes it moves rather than with the dense figure."""
-    fr = []
-    for hist, mask, cand, _ in batches:
-        B, H = mask.shape
-        C = cand.shape[1]
-        nz = torch.cat([torch.ones(B * C, device=mask.device), (mask.reshape(-1) != 0).float()])
-        allpad = torch.cat([(cand == 0).all(-1).reshape(-1), (hist == 0).all(-1).reshape(-1)])
-        near = torch.nn.functional.max_pool1d(nz[None, None], kernel_size=7, stride=1, padding=3)[0, 0] > 0
-        keep = ~(allpad & ~near)
-        fr.append(float(keep.float().mean()))
-    return sum(fr) / len(fr)
-
-
-def roofline_of(prof, dtype, live_frac=1.0):
-    """Pick the kernel with the largest total time in the timed region and price it."""
+def roofline_of(prof, dtype, struct):
+    """The kernel with the largest total time in the timed region, priced."""
     if not prof:
         return None
     label, (cnt, ms) = max(prof.items(), key=lambda kv: kv[1][1])
-    avg_s = ms / cnt / 1e3
-    esz = 2 if dtype == "bf16" else 4
-    if label.startswith("gemm") and "_live[" not in label:      # "_live": row count known on the device only
-        fl = gemm_flops(label)
-        peak = PEAK_MFMA_BF16 if "bf16" in label else PEAK_MFMA_F32
-        ach = fl / avg_s / 1e12
-        return {"kernel": label, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": pmc_traffic(label), "avg_ms": round(ms / cnt, 4), "launches": cnt,
-                "algorithmic_flops": fl}
-    if label.startswith("attn"):
-        by = attn_bytes(label, esz)
-        if "_live[" in label:
-            by = int(by * live_frac)
-        ach = by / avg_s / 1e9
-        return {"kernel": label, "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM, "unit": "GB/s",
-                "frac": round(ach / PEAK_HBM, 4), "traffic": pmc_traffic(label), "avg_ms": round(ms / cnt, 4), "launches": cnt,
-                "algorithmic_bytes": by}
-    return {"kernel": label, "bound": "hbm", "achieved": None, "peak": PEAK_HBM, "unit": "GB/s", "frac": None,
-            "traffic": None, "avg_ms": round(ms / cnt, 4), "launches": cnt}
+    pr = price_kernel(label, ms / cnt, struct, dtype)
+    out = {"kernel": label, "avg_ms": round(ms / cnt, 4), "launches": cnt, "traffic": pmc_traffic(label)}
+    if pr is None:
+        out.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM, "unit": "GB/s", "frac": None})
+        return out
+    out.update({"bound": pr["bound"], "achieved": pr["achieved"], "peak": pr["peak"], "unit": pr["unit"],
+                "frac": round(pr["achieved"] / pr["peak"], 4),
+                ("algorithmic_flops" if pr["bound"] == "mfma" else "algorithmic_bytes"): int(pr["work"])})
+    return out
 
 
-def cpu_baseline(args, V, seed):
-    """The CPU oracle (oracle/nr_oracle.py, torch-CPU fp32) on a bounded sample of the same workload:
-    NRMS train step (fwd + bwd + Adam, Bernoulli dropout masks drawn per step) at B=64, 1 warm-up + 3 timed."""
+def step_roofline(model_name, dtype, batch, ms_per_step):
+    """Whole training step against the binding bound of SURVEY §8(d): algorithmic FLOPs (3 x forward) / time / dense MFMA
+    peak, and the HBM bytes a step moves (sum over all dispatches of the committed PMC passes) against the fused minimum
+    (forward minimum x 3: activations are read again and their gradients written in the backward)."""
+    fl = 3.0 * FWD_GFLOP_PER_IMP[model_name] * 1e9 * batch
+    peak = PEAK_MFMA_BF16 if dtype == "bf16" else PEAK_MFMA_F32
+    out = {"bound": "mfma", "algorithmic_flops": fl, "achieved": round(fl / (ms_per_step / 1e3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s"}
+    out["frac"] = round(out["achieved"] / peak, 4)
+    pm = pmc_file()
+    fused_min = 3.0 * FUSED_MIN_BYTES_PER_IMP_FWD[dtype] * batch
+    out["fused_min_bytes"] = int(fused_min)
+    tot = pm.get("step_total") if pm else None
+    if tot and tot.get("model") == model_name and tot.get("dtype") == dtype and tot.get("batch") == batch:
+        out["hbm_bytes_per_step_pmc"] = int(tot["bytes_per_step"])
+        out["wasted_traffic_ratio"] = round(tot["bytes_per_step"] / fused_min, 2)
+        out["hbm_frac_of_peak_at_measured_time"] = round(tot["bytes_per_step"] / (ms_per_step / 1e3) / 1e9 / PEAK_HBM, 4)
+    return out
+
+
+# ----------------------------------------------------------------------------------------- CPU baseline
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(args, V, seed, B=512, budget_s=30.0):
+    """The CPU oracle (oracle/nr_oracle.py, torch-CPU fp32) on the SAME workload: NRMS train step (fwd + bwd + Adam,
+    Bernoulli dropout masks drawn per step) at B = 512, threads = physical cores.  Bounded sample: one warm-up
+    step, then as many timed steps (1..5) as fit ~30 s."""
     from oracle import nr_oracle as O
-    Bs = 64
+    cores = physical_cores()
+    torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(seed)
     table = torch.randn(V, args.word_embedding_dim, generator=g) * 0.4
     table[0] = 0
     sd = O.init_state_dict("NRMS", args, table, seed=0)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     opt = torch.optim.Adam(params.values(), lr=1e-4)
-    hist, mask, cand, label = synth_batches(args, Bs, V, 1, seed + 1, "cpu")[0]
+    hist, mask, cand, label = synth_batches(args, B, V, 1, seed + 1, "cpu")[0]
     T, N, p = args.num_words_title, args.news_dim, args.drop_rate
 
     def step():
-        keep = {"cand_word": torch.bernoulli(torch.full((Bs * 5, T, 300), 1 - p)),
-                "cand_ctx": torch.bernoulli(torch.full((Bs * 5, T, N), 1 - p)),
-                "hist_word": torch.bernoulli(torch.full((Bs * 50, T, 300), 1 - p)),
-                "hist_ctx": torch.bernoulli(torch.full((Bs * 50, T, N), 1 - p))}
+        keep = {"cand_word": torch.bernoulli(torch.full((B * 5, T, 300), 1 - p)),
+                "cand_ctx": torch.bernoulli(torch.full((B * 5, T, N), 1 - p)),
+                "hist_word": torch.bernoulli(torch.full((B * 50, T, 300), 1 - p)),
+                "hist_ctx": torch.bernoulli(torch.full((B * 50, T, N), 1 - p))}
         loss, _ = O.nrms_forward(hist, mask, cand, label, params, args, keep=keep)
         opt.zero_grad()
         loss.backward()
         opt.step()
 
-    step()
     t0 = time.perf_counter()
-    n = 3
+    step()
+    warm = time.perf_counter() - t0
+    n = max(1, min(5, int(budget_s / max(warm, 1e-3))))
+    t0 = time.perf_counter()
     for _ in range(n):
         step()
     dt = time.perf_counter() - t0
-    return {"value": round(Bs * n / dt, 2), "unit": "impressions/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"NRMS train step (fwd+bwd+Adam, dropout 0.2) at B={Bs}, {n} timed steps after 1 warm-up, torch-CPU fp32"}
+    return {"value": round(B * n / dt, 2), "unit": "impressions/s", "cores": cores, "kind": "port",
+            "sample": f"NRMS train step (fwd+bwd+Adam, dropout 0.2) at B={B}, {n} timed step(s) after 1 warm-up "
+                      f"({warm:.1f} s), torch-CPU fp32, {cores} threads (physical cores)"}
+
+
+def cpu_eval_baseline(args, V, n_news, n_imp, seed, budget_s=20.0):
+    """The oracle's eval path on a bounded sample: encode a slice of the corpus, score + rank a slice of the impressions."""
+    from oracle import nr_oracle as O
+    import numpy as np
+    cores = physical_cores()
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(seed)
+    table = torch.randn(V, args.word_embedding_dim, generator=g) * 0.4
+    table[0] = 0
+    sd = O.init_state_dict("NRMS", args, table, seed=0)
+    ev = SimpleNamespace(**vars(args))
+    ev.user_log_mask = True
+    comb = synth_news_table(args, 4096, V, seed + 1)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        nv = O.nrms_news_encoder(comb[:2048], sd, ev)
+        t_news = (time.perf_counter() - t0) / 2048
+        nv = torch.cat([nv, nv])[: comb.shape[0]]
+        rnd = np.random.RandomState(seed)
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < budget_s / 2 and k < 4000:
+            B = 64
+            hist = torch.from_numpy(rnd.randint(0, comb.shape[0], (B, 50)))
+            mask = torch.from_numpy((rnd.rand(B, 50) < 0.6).astype("float32"))
+            uv = O.nrms_user_encoder(nv[hist], mask, sd, ev)
+            for b in range(B):
+                c = rnd.randint(2, 101)
+                s = (nv[torch.from_numpy(rnd.randint(0, comb.shape[0], c))] @ uv[b]).numpy()
+                y = (rnd.rand(c) < 0.15).astype("int64")
+                if y.mean() not in (0, 1):
+                    O.auc_score(y, s), O.mrr_score(y, s), O.ndcg_score(y, s, 5), O.ndcg_score(y, s, 10)
+            k += B
+        t_imp = (time.perf_counter() - t0) / max(k, 1)
+    total = t_news * n_news + t_imp * n_imp
+    return {"value": round(n_imp / total, 2), "unit": "impressions/s", "cores": cores, "kind": "port",
+            "sample": f"oracle eval path extrapolated from 2048 encoded news ({t_news * 1e3:.2f} ms/news) and {k} scored + ranked "
+                      f"impressions ({t_imp * 1e3:.2f} ms/impression) to {n_news} news + {n_imp} impressions, {cores} threads"}
+
+
+class ArrayShard:
+    """Synthetic stand-in with the field contract of data.IndexedTrainShard / IndexedTestShard (index arrays, no files)."""
+
+    def __init__(self, n, **arrays):
+        self.n = n
+        self.__dict__.update(arrays)
+
+    def __len__(self):
+        return self.n
+
+    def draw_labels(self):
+        import random
+        import numpy as np
+        return np.fromiter((random.randint(0, self.npratio) for _ in range(self.n)), dtype=np.int64, count=self.n)
+
+
+# ----------------------------------------------------------------------------------------- eval workload
+def run_eval(a, args, device, rank, world, dist_on):
+    """BASELINE configs[4], one GPU's share: encode the news corpus once (sharded over the ranks + all_gather when N > 1),
+    then score `--eval-impressions` impressions (candidates ~U[2,100]) and rank them, all on the device."""
+    import numpy as np
+    import torch.distributed as dist
+    from newsrecommendation_amd import _lib, train as TR
+    from newsrecommendation_amd.model import NRMS
+    args.user_log_mask = True                                # src/demo.sh:26 evaluates with the masked user encoder
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1)
+    table = torch.randn(a.vocab, args.word_embedding_dim, generator=g) * 0.4
+    table[0] = 0
+    model = NRMS.Model(args, table.numpy()).to(device).eval()
+    comb = synth_news_table(args, a.eval_news, a.vocab, 3).numpy()
+    rnd = np.random.RandomState(10 + rank)
+    n = a.eval_impressions
+    counts = rnd.randint(2, 101, n)
+    off = np.zeros(n + 1, dtype=np.int32)
+    off[1:] = np.cumsum(counts)
+    hl = rnd.randint(0, 51, n)
+    hist = rnd.randint(1, a.eval_news + 1, (n, 50)).astype(np.int32)
+    mask = (np.arange(50)[None, :] >= (50 - hl)[:, None]).astype(np.float32)
+    hist[mask == 0] = 0
+    sh = ArrayShard(n, hist=hist, mask=mask, cand=rnd.randint(1, a.eval_news + 1, off[-1]).astype(np.int32),
+                    label=(rnd.rand(off[-1]) < 0.1).astype(np.int32), offsets=off)
+
+    def fence():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_pass():
+        nv = TR.encode_news(model, comb, a.eval_batch, device, shard_over_ranks=dist_on)
+        scores, sums = TR.score_shard(model, nv, sh, a.eval_batch, device)
+        return sums
+
+    for _ in range(a.warmup):
+        one_pass()
+    fence()
+    prof_on = (not a.no_prof) and rank == 0
+    if prof_on:
+        _lib.prof_enable(2)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sums = one_pass()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = {}
+    if prof_on:
+        _lib.prof_enable(False)
+        prof = _lib.prof_collect()
+    if dist_on:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    sums = sums.cpu().tolist()
+    struct = {"live_token_rows": float((comb != 0).mean()), "live_gradient_slabs": 1.0, "attention_bwd_sequences": 1.0}
+    out = {"metric": "eval impressions/sec (full-corpus encode + scoring + ranking metrics), NRMS", "value": round(n * world * a.steps / dt, 1),
+           "unit": "impressions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": f"NRMS eval: encode {a.eval_news} news (sharded over ranks) + score {n} impressions per GPU, candidates ~U[2,100], "
+                                  "history 50, user_log_mask=True; AUC/MRR/nDCG on the device",
+                      "news": a.eval_news, "impressions_per_gpu": n, "candidates": int(off[-1]), "eval_batch": a.eval_batch, "parallelism": f"dp{world}",
+                      "scored_impressions": int(sums[0]), "mean_auc": round(sums[1] / max(sums[0], 1), 4)}}
+    out["roofline"] = roofline_of(prof, a.dtype, struct)
+    if prof:
+        out["kernel_ms_per_step"] = {k: round(ms / a.steps, 4) for k, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:10]}
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_eval_baseline(make_args("fp32"), a.vocab, a.eval_news, n, 7)
+    print(json.dumps(out))
 
 
 def main():
@@ -205,12 +439,22 @@ def main():
                     help="NRMS = the headline config; NAML = BASELINE config[2] (multi-view, frozen [N+1, T*D] title table)")
     ap.add_argument("--naml-news", type=int, default=65000)
     ap.add_argument("--freeze-embedding", action="store_true")
+    ap.add_argument("--dense-batch", action="store_true", help="full histories and full-length titles (no padding)")
+    ap.add_argument("--feed", default="resident", choices=["resident", "device"],
+                    help="resident: 4 pre-built batches cycle (the headline); device: every step assembles a NEW batch on the device "
+                         "from news-index arrays (train.DeviceFeed, SURVEY §8 row f1)")
+    ap.add_argument("--dp-mode", default="flat", choices=["flat", "ddp"],
+                    help="flat: parallel.FlatBucket (one all-reduce + fused HIP Adam); ddp: DistributedDataParallel + torch.optim.Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--compact-history", action="store_true",
                     help="opt-in: encode only history slots with mask != 0 (their vectors reach the loss through a factor 0); "
                          "NOT the headline configuration -- the reference encodes all 55 titles per impression")
     ap.add_argument("--all-kernels", action="store_true", help="list every kernel label in kernel_ms_per_step (default: top 12)")
+    ap.add_argument("--eval", action="store_true", help="eval workload (BASELINE configs[4]) instead of the train step")
+    ap.add_argument("--eval-news", type=int, default=100000)
+    ap.add_argument("--eval-impressions", type=int, default=125000, help="impressions per GPU (1M over 8 GPUs)")
+    ap.add_argument("--eval-batch", type=int, default=2048)
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,10 +469,17 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)   # 'nccl' == RCCL on ROCm (src/main.py:31)
 
-    from newsrecommendation_amd import _lib
+    from newsrecommendation_amd import _lib, parallel, train as TR
     from newsrecommendation_amd.model import NAML, NRMS
 
     args = make_args(a.dtype)
+    if a.eval:
+        if a.steps == 20 and a.warmup == 5:
+            a.steps, a.warmup = 3, 1
+        run_eval(a, args, device, rank, world, dist_on)
+        if dist_on:
+            dist.destroy_process_group()
+        return
     args.freeze_embedding = bool(a.freeze_embedding)
     args.compact_history = bool(a.compact_history)
     torch.manual_seed(0)
@@ -244,22 +495,46 @@ def main():
         table[0] = 0
         model = NAML.Model(args, table.numpy(), 17, 264).to(device)
     model.train()
-    # src/main.py:76 (defaults); fused=True is the same update rule in one multi-tensor kernel instead of ~6
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
-    net = model
-    if dist_on:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])   # src/main.py:82
-    if a.model == "NRMS":
-        batches = synth_batches(args, a.batch, a.vocab, 4, 100 + rank, device)
+    net, bucket, opt = model, None, None
+    if a.dp_mode == "flat":
+        bucket = parallel.FlatBucket(model, lr=1e-4)       # rank-0 broadcast; per step ONE all-reduce + ONE fused Adam kernel
     else:
-        batches = synth_batches_naml(args, a.batch, a.naml_news, 4, 100 + rank, device)
+        # src/main.py:76 (defaults); fused=True is the same update rule in one multi-tensor kernel instead of ~6
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+        if dist_on:
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])   # src/main.py:82
+    if a.model == "NRMS":
+        batches = synth_batches(args, a.batch, a.vocab, 4, 100 + rank, device, dense=a.dense_batch)
+    else:
+        batches = synth_batches_naml(args, a.batch, a.naml_news, 4, 100 + rank, device, dense=a.dense_batch)
+
+    feed = None
+    if a.feed == "device":
+        if a.model != "NRMS":
+            raise SystemExit("--feed device is wired for NRMS inputs")
+        import numpy as np
+        n_news, n_lines = 65000, a.batch * (a.steps + a.warmup)
+        comb = synth_news_table(args, n_news, a.vocab, 3).numpy()
+        rnd = np.random.RandomState(100 + rank)
+        hl = np.full(n_lines, 50) if a.dense_batch else rnd.randint(0, 51, n_lines)
+        hist = rnd.randint(1, n_news + 1, (n_lines, 50)).astype(np.int32)
+        mask = (np.arange(50)[None, :] >= (50 - hl)[:, None]).astype(np.float32)
+        hist[mask == 0] = 0
+        sh = ArrayShard(n_lines, hist=hist, mask=mask, pos=rnd.randint(1, n_news + 1, n_lines).astype(np.int32),
+                        neg=rnd.randint(1, n_news + 1, (n_lines, 4)).astype(np.int32), npratio=4)
+        feed = TR.DeviceFeed(sh, comb, a.batch, device)
+        feed.start_epoch()
 
     def step(i):
-        hist, mask, cand, label = batches[i % len(batches)]
+        hist, mask, cand, label = feed.batch(i) if feed is not None else batches[i % len(batches)]
         loss, score = net(hist, mask, cand, label)
-        opt.zero_grad()
+        if opt is not None:
+            opt.zero_grad()
         loss.backward()
-        opt.step()
+        if bucket is not None:
+            bucket.step()
+        else:
+            opt.step()
         return loss
 
     def fence():
@@ -292,21 +567,35 @@ def main():
 
     if rank == 0:
         total = a.batch * world * a.steps
+        ms_step = dt / a.steps * 1e3
+        if feed is not None:
+            batches = [feed.batch(i) for i in range(a.warmup, a.warmup + 4)]
+        struct = batch_structure(batches, args, a.model)
         out = {"metric": f"train impressions/sec @ batch {a.batch}, " + a.model, "value": round(total / dt, 1), "unit": "impressions/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                "config": {"workload": a.model + " train step (fwd+bwd+Adam), MIND-small shapes: title_len=30, history=50, "
-                                      "npratio=4, 300-d " + ("word table" if a.model == "NRMS" else "per-news title rows, 3 views"),
+                                      "npratio=4, 300-d " + ("word table" if a.model == "NRMS" else "per-news title rows, 3 views")
+                                      + (", DENSE batch (no padding)" if a.dense_batch else ""),
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "vocab_rows": a.vocab,
                           "dropout": args.drop_rate, "freeze_embedding": args.freeze_embedding,
-                          "compact_history": bool(a.compact_history),
-                          "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)}}
-        out["roofline"] = roofline_of(prof, a.dtype, live_sequence_fraction(batches, args) if a.model == "NRMS" else 1.0)
+                          "compact_history": bool(a.compact_history), "dense_batch": bool(a.dense_batch), "feed": a.feed,
+                          "optimizer": "flat bucket + HIP fused Adam" if bucket is not None else "DDP + torch.optim.Adam(fused)",
+                          "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "batch_structure": struct}}
+        out["roofline"] = roofline_of(prof, a.dtype, struct)
+        if out["roofline"] is not None:
+            out["roofline"]["step"] = step_roofline(a.model, a.dtype, a.batch, ms_step)
         if prof:
             tot = sum(ms for _, ms in prof.values())
-            out["kernel_ms_per_step"] = {k: round(ms / a.steps, 4) for k, (c, ms) in
-                                         sorted(prof.items(), key=lambda kv: -kv[1][1])[:(None if a.all_kernels else 12)]}
+            top = sorted(prof.items(), key=lambda kv: -kv[1][1])[:(None if a.all_kernels else 12)]
+            out["kernel_ms_per_step"] = {k: round(ms / a.steps, 4) for k, (c, ms) in top}
             out["kernel_ms_per_step"]["_all_timed_libnrhip_kernels"] = round(tot / a.steps, 4)
+            fr = {}
+            for k, (c, ms) in top:
+                pr = price_kernel(k, ms / c, struct, a.dtype)
+                if pr is not None:
+                    fr[k] = {"bound": pr["bound"], "frac": round(pr["achieved"] / pr["peak"], 3)}
+            out["kernel_roofline_frac"] = fr
         if world == 1 and not a.no_cpu_baseline and a.model == "NRMS":
             out["cpu_baseline"] = cpu_baseline(args, a.vocab, 7)
         print(json.dumps(out))

@@ -89,7 +89,7 @@ def test_train_loop_tracks_oracle_and_eval_matches(tmp_path, dp_mode, feed):
     n_seen, means = TR.test(None, args_eval, model, news_index, news_combined, log=lambda *_: None, collect_scores=got)
     sd = {k: v.detach().cpu().float() for k, v in model.state_dict().items()}
     nv = O.nrms_news_encoder(torch.from_numpy(news_combined), sd, args_eval)
-    sums, cnt = np.zeros(4), 0
+    sums, cnt, tie_free = np.zeros(4), 0, 0
     lines = open(os.path.join(args.test_data_dir, "behaviors_0.tsv")).readlines()
     assert n_seen == 200 == len(got)
     for line, (lab_g, s_g) in zip(lines, got):
@@ -100,10 +100,21 @@ def test_train_loop_tracks_oracle_and_eval_matches(tmp_path, dp_mode, feed):
         assert np.allclose(s_g, s, atol=1e-4), float(np.abs(s_g - s).max())          # device scores vs oracle scores
         if labels.mean() in (0, 1):
             continue
-        # rank metrics are discontinuous in the scores (near-ties): compare both implementations on the SAME scores
-        sums += [O.auc_score(labels, s_g), O.mrr_score(labels, s_g), O.ndcg_score(labels, s_g, 5), O.ndcg_score(labels, s_g, 10)]
+        # rank metrics are discontinuous in the scores (near-ties): compare both implementations on the SAME scores.
+        # Duplicate candidates of an impression have EQUAL scores; numpy's default argsort (src/metrics.py:6,20) leaves
+        # their order unspecified, the device kernel uses the stable order reversed -- restated here.
+        order = np.argsort(s_g, kind="stable")[::-1]
+        yt = labels[order]
+        dcg = lambda k: np.sum((2 ** yt[:k] - 1) / np.log2(np.arange(len(yt[:k])) + 2))
+        row = [O.auc_score(labels, s_g), np.sum(yt / (np.arange(len(yt)) + 1)) / yt.sum(), dcg(5) / O.dcg_score(labels, labels, 5),
+               dcg(10) / O.dcg_score(labels, labels, 10)]
+        if len(np.unique(s_g)) == len(s_g):               # no ties: exactly the reference's functions
+            assert np.allclose(row, [O.auc_score(labels, s_g), O.mrr_score(labels, s_g), O.ndcg_score(labels, s_g, 5),
+                                     O.ndcg_score(labels, s_g, 10)], atol=1e-12)
+            tie_free += 1
+        sums += row
         cnt += 1
-    assert cnt > 50
+    assert cnt > 50 and tie_free > 20
     assert np.allclose(means, sums / cnt, atol=1e-9), (means, sums / cnt)
 
 
