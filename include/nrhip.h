@@ -126,6 +126,11 @@ typedef struct {
                          (their dQ|dK|dV rows stay unwritten and are never read).  No host synchronisation.  NULL: every row
                          goes through the GEMMs.                    */
   size_t row_ws_bytes; /* size of row_ws in bytes: must be >= nr_mhsa_workspace_bytes(d) when row_ws != NULL (checked) */
+  const void* proj_table; /* nr_mhsa_fwd only, optional [V, 3N] dtype = table . W_qkv^T + b_qkv (one nr_gemm_nt over the table):
+                         eval mode (p_in == 0, bf16 gather source, qkv == NULL, no backward) gathers the projections of a token
+                         from here instead of projecting every occurrence -- same values, ~V/(n*L) of the GEMM work */
+  const int32_t* seq_nz; /* nr_mhsa_bwd only, optional [n]: 0 = the upstream gradient dy of this sequence is exactly zero (the flags
+                         nr_additive_pool_bwd leaves in its workspace, see nr_pool_seq_flags); NULL: the library scans dy itself */
   int row_ws_ready;   /* nr_mhsa_bwd only: nonzero = row_ws still holds what nr_mhsa_fwd wrote for these ids (reused as is).
                          REQUIRED when nr_mhsa_fwd was given row_ws: on the bf16 title-level path the forward then leaves
                          the qkv rows of all-padding sequences unwritten (the attention kernels substitute the bias), and the
@@ -186,6 +191,7 @@ typedef struct {
                          titles whose upstream gradient dy is not all zero and contracts only the 32-row slabs that touch
                          one (masked history slots have an exactly zero dy).  NULL: every row is contracted.          */
   size_t bwd_ws_bytes; /* size of bwd_ws in bytes, >= nr_conv_workspace_bytes(d) when bwd_ws != NULL (checked)              */
+  const int32_t* seq_nz; /* nr_conv1d_k3_bwd only, optional [n]: 0 = dy of this title is exactly zero (see nr_pool_seq_flags)  */
 } nr_conv_desc;
 size_t nr_conv_workspace_bytes(const nr_conv_desc* d);
 int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream);
@@ -209,6 +215,10 @@ typedef struct {
 } nr_pool_desc;
 /* Bytes of the `partial` workspace of nr_additive_pool_bwd. */
 size_t nr_pool_workspace_bytes(const nr_pool_desc* d);
+/* After nr_additive_pool_bwd (bf16, L <= 32, rows a multiple of 32): the [n] int32 flags inside `partial` that say which
+ * sequences had a non-zero pooled gradient g -- exactly the sequences whose dx rows are non-zero.  The producer of x can
+ * take them as its `seq_nz` instead of scanning dx.  Returns NULL when this descriptor does not produce flags.        */
+const int32_t* nr_pool_seq_flags(const nr_pool_desc* d, const float* partial);
 /* e: [n*L, q] dtype (tanh output, saved); alpha: [n*L] fp32 (saved); out: fp32, row i at out + i*ld_out. */
 int nr_additive_pool_fwd(const nr_pool_desc* d, void* e, float* alpha, float* out, int ld_out, nr_stream_t stream);
 /* g: fp32 d(out), row i at g + i*ld_g.  w1_t [N, ldw1t] dtype = w1^T.  dpre: workspace [n*L, q] dtype.

@@ -28,14 +28,14 @@ class MhsaDesc(C.Structure):
                 ("p_in", C.c_float), ("seed_in", C.c_uint32), ("p_out", C.c_float), ("seed_out", C.c_uint32),
                 ("mask", C.c_void_p), ("w_qkv", C.c_void_p), ("ldw", C.c_int), ("b_qkv", C.c_void_p),
                 ("x_rows", C.c_void_p), ("ld_rows", C.c_int), ("row_ws", C.c_void_p), ("row_ws_bytes", C.c_size_t),
-                ("row_ws_ready", C.c_int)]
+                ("proj_table", C.c_void_p), ("seq_nz", C.c_void_p), ("row_ws_ready", C.c_int)]
 
 
 class ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("T", C.c_int), ("D", C.c_int), ("Dp", C.c_int), ("N", C.c_int), ("dtype", C.c_int),
                 ("table", C.c_void_p), ("ids", C.c_void_p), ("ids_stride", C.c_int), ("p_in", C.c_float),
                 ("seed_in", C.c_uint32), ("w_pack", C.c_void_p), ("bias", C.c_void_p), ("x_rows", C.c_void_p),
-                ("ld_rows", C.c_int), ("bwd_ws", C.c_void_p), ("bwd_ws_bytes", C.c_size_t)]
+                ("ld_rows", C.c_int), ("bwd_ws", C.c_void_p), ("bwd_ws_bytes", C.c_size_t), ("seq_nz", C.c_void_p)]
 
 
 class PoolDesc(C.Structure):
@@ -52,7 +52,7 @@ class LinearDesc(C.Structure):
 
 _vp, _i, _f, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_uint32
 # name -> argtypes ; every entry returns int unless listed in RESTYPES.  Must list exactly the symbols of include/nrhip.h.
-RESTYPES = {"nr_eval_metrics_workspace_bytes": C.c_size_t, "nr_mhsa_workspace_bytes": C.c_size_t, "nr_conv_workspace_bytes": C.c_size_t, "nr_pool_workspace_bytes": C.c_size_t,
+RESTYPES = {"nr_pool_seq_flags": C.c_void_p, "nr_eval_metrics_workspace_bytes": C.c_size_t, "nr_mhsa_workspace_bytes": C.c_size_t, "nr_conv_workspace_bytes": C.c_size_t, "nr_pool_workspace_bytes": C.c_size_t,
             "nr_linear_workspace_bytes": C.c_size_t}
 SIGNATURES = {
     "nr_version": [],
@@ -63,6 +63,7 @@ SIGNATURES = {
     "nr_mhsa_workspace_bytes": [C.POINTER(MhsaDesc)],
     "nr_conv_workspace_bytes": [C.POINTER(ConvDesc)],
     "nr_pool_workspace_bytes": [C.POINTER(PoolDesc)],
+    "nr_pool_seq_flags": [C.POINTER(PoolDesc), _vp],
     "nr_linear_workspace_bytes": [C.POINTER(LinearDesc)],
     "nr_sdpa_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u32, _vp],
     "nr_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u32, _vp],

@@ -11,6 +11,8 @@ int nr_launch_attn(bool bwd, int dtype, const void* qkv, const float* mask, void
                    int heads, int d_head, const DropCfg& drop, hipStream_t stream, const uint32_t* tmask = nullptr,
                    const float* bias = nullptr, const int32_t* seq_list = nullptr, const int32_t* seq_count = nullptr);
 bool nr_attn_pad_ok(int dtype, int L, int d_head, const void* p0, const void* p1);
+int nr_launch_attn_gather_fwd(const void* proj_table, const int32_t* ids, const float* mask, void* y, int n, int L, int heads,
+                              int d_head, const DropCfg& drop, hipStream_t stream);
 int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
                             float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s);
 int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float* w2, const float* alpha, const float* g,
@@ -209,6 +211,11 @@ int nr_pool_partial_rows(int n);
 static size_t pool_ws_used(int n, int q) { return ((size_t)nr_pool_partial_rows(n) * (q + 1) + 3) / 4 * 4; }
 static size_t pool_ws_elems(int n, int L, int q) { return pool_ws_used(n, q) + (size_t)n + 8 + ((size_t)n * L) / 32 + 4; }
 
+static bool pool_has_flags(const nr_pool_desc* d) {
+  const int M = d->n * d->L;
+  return !nr_opt(NR_OPT_NO_SLABS) && d->dtype == NR_BF16 && M % 32 == 0 && d->L <= 32 && nr_gemm_tn_slabs_ok(d->q, d->N, M, d->q, d->N);
+}
+
 static int mhsa_check(const nr_mhsa_desc* d) {
   NR_CHECK_ARG(d != nullptr, "mhsa: null descriptor");
   NR_CHECK_ARG(dtype_ok(d->dtype), "mhsa: bad dtype %d", d->dtype);
@@ -311,6 +318,10 @@ size_t nr_conv_workspace_bytes(const nr_conv_desc* d) {
 }
 size_t nr_pool_workspace_bytes(const nr_pool_desc* d) {
   return (d == nullptr || d->n < 0 || d->L < 1 || d->q < 1) ? 0 : pool_ws_elems(d->n, d->L, d->q) * sizeof(float);
+}
+const int32_t* nr_pool_seq_flags(const nr_pool_desc* d, const float* partial) {
+  if (d == nullptr || partial == nullptr || d->n <= 0 || d->L < 1 || d->q < 1 || !dtype_ok(d->dtype) || !pool_has_flags(d)) return nullptr;
+  return reinterpret_cast<const int32_t*>(partial + pool_ws_used(d->n, d->q));
 }
 size_t nr_linear_workspace_bytes(const nr_linear_desc* d) {
   if (d == nullptr || d->M < 0 || d->N < 1 || !dtype_ok(d->dtype)) return 0;
@@ -428,6 +439,15 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   const MhsaWs W = mhsa_ws_layout(d->n, d->L);
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
+  if (d->proj_table != nullptr) {
+    // Eval mode (no input dropout): Q|K|V of a token are W x + b of its table row -- a function of the token id alone.  The
+    // caller projected the whole table once (nr_gemm_nt over [V, d_model]); the attention kernel gathers projected rows.
+    NR_CHECK_ARG(d->src_kind == NR_SRC_GATHER && d->p_in == 0.f && d->dtype == NR_BF16 && d->ids != nullptr && qkv == nullptr,
+                 "mhsa_fwd: proj_table needs a bf16 gather source without input dropout and no qkv buffer (no backward)");
+    rc = nr_launch_attn_gather_fwd(d->proj_table, d->ids, d->mask, y, d->n, d->L, d->heads, d->d_head, nr_make_drop(d->p_out, d->seed_out), s);
+    NR_CHECK_ARG(rc >= 0, "mhsa_fwd: proj_table is only supported for L <= 32, d_head %% 4 == 0, 8-byte aligned tensors");
+    return rc;
+  }
   if (qkv == nullptr && d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER) {
     // Inference (no backward -> the caller passes no qkv buffer): one fused kernel, gather + projection + attention with
     // Q|K|V kept on chip.  Measured on MI355X it ties the unfused chain in time (2.8 ms per 28 160 titles) and saves
@@ -497,7 +517,11 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
       M >= 4096 && nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, dqkv) && (((uintptr_t)dy) & 7) == 0 &&
       nr_gemm_tn_slabs_ok(3 * N, d->ld_rows, M, 3 * N, Kp)) {
     slab_ws = d->row_ws + W.slab;
-    if ((rc = nr_launch_title_flags(dy, d->n, d->L, N, slab_ws, s))) return rc;    // one pass over dy (bf16 [M, N])
+    if (d->seq_nz != nullptr) {                    // the consumer of y already knows which sequences got a gradient
+      NR_CHECK_HIP(hipMemcpyAsync(slab_ws, d->seq_nz, (size_t)d->n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    } else if ((rc = nr_launch_title_flags(dy, d->n, d->L, N, slab_ws, s))) {      // one pass over dy (bf16 [M, N])
+      return rc;
+    }
     if ((rc = nr_launch_live_slabs(slab_ws, d->n, d->L, s))) return rc;
     const bool no_skip = nr_opt(NR_OPT_NO_ATTN_SKIP) != 0;
     if (tmask != nullptr && !no_skip) {
@@ -613,7 +637,11 @@ int nr_conv1d_k3_bwd(const nr_conv_desc* d, const void* dy, float* dw_pack, floa
     if (!no_slabs && d->bwd_ws != nullptr && d->dtype == NR_BF16 && M % 32 == 0 && d->T <= 32 && d->N % 8 == 0 &&
         (((uintptr_t)dy) & 15) == 0 && nr_gemm_tn_slabs_ok(d->N, d->ld_rows, M, d->N, 3 * d->Dp)) {
       hipStream_t s = (hipStream_t)stream;
-      if ((rc = nr_launch_title_flags(dy, d->n, d->T, d->N, d->bwd_ws, s))) return rc;
+      if (d->seq_nz != nullptr) {
+        NR_CHECK_HIP(hipMemcpyAsync(d->bwd_ws, d->seq_nz, (size_t)d->n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+      } else if ((rc = nr_launch_title_flags(dy, d->n, d->T, d->N, d->bwd_ws, s))) {
+        return rc;
+      }
       if ((rc = nr_launch_live_slabs(d->bwd_ws, d->n, d->T, s))) return rc;
       return nr_launch_gemm_tn_slabs(dy, d->N, d->x_rows, d->ld_rows, dw_pack, 3 * d->Dp, db, M, d->N, 3 * d->Dp, d->N, 3 * d->Dp,
                                      d->bwd_ws + d->n + 4, d->bwd_ws + d->n, s);
@@ -666,9 +694,8 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
   // so ds = 0 and its dpre rows are exact zeros: the core kernel only writes those zeros for it, and the att_fc1 weight
   // gradient contracts only the 32-row slabs that touch a sequence with g != 0.  The int scratch (n flags, count, M/32
   // slab ids) lives in the unused tail of `partial` (its first nr_pool_partial_rows(n) rows are taken).
-  const bool no_slabs = nr_opt(NR_OPT_NO_SLABS) != 0;
   int32_t* ws = nullptr;
-  if (!no_slabs && d->dtype == NR_BF16 && M % 32 == 0 && d->L <= 32 && nr_gemm_tn_slabs_ok(d->q, d->N, M, d->q, d->N)) {
+  if (pool_has_flags(d)) {
     ws = reinterpret_cast<int32_t*>(partial + pool_ws_used(d->n, d->q));   // the int scratch behind the partial rows
     if ((rc = nr_launch_row_flags_f32(g, ld_g, d->N, d->n, ws, s))) return rc;
   }

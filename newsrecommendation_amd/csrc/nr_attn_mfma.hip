@@ -41,6 +41,8 @@ struct AttnMArgs {
   const int32_t* seq_count;  //   out have exactly zero dQ|dK|dV rows that nothing downstream reads
   const uint32_t* tmask;  // optional [n]: live-token bit mask of each sequence.  0 = padding tokens only: every Q|K|V row
   const float* bias;      //   of that sequence is this bias [3N]; its qkv rows are never written and never read
+  const int32_t* ids;     // optional (forward, bf16 panel kernel) [n*L]: row m of Q|K|V is qkv[ids[m]] -- `qkv` is then a
+                          //   per-token-id table of projections (eval mode: W x + b depends on the token id only)
 };
 
 __device__ __forceinline__ int rowof(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -612,6 +614,16 @@ __device__ __forceinline__ void panel_load(Panel<PT>& r, const bf16_t* __restric
     if (pc.hh(t) < hcount) r.v[t] = *reinterpret_cast<const bf16x4*>(src + (uint32_t)(pc.row(t) * ld + pc.q4(t)));
   }
 }
+// row-indirect variant: token row r of the sequence lives at table row ids[r] (ids points at the sequence's first token)
+template <int PT>
+__device__ __forceinline__ void panel_load_g(Panel<PT>& r, const bf16_t* __restrict__ table, int ld, const int32_t* __restrict__ ids,
+                                             int coff, const Pieces<PT>& pc, int hcount) {
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    r.v[t] = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (pc.hh(t) < hcount) r.v[t] = *reinterpret_cast<const bf16x4*>(table + (size_t)ids[pc.row(t)] * ld + coff + pc.q4(t));
+  }
+}
 template <bool DROP, int PT>
 __device__ __forceinline__ void panel_put(const Panel<PT>& r, bf16_t* img0, const Pieces<PT>& pc, const DropCfg& drop, uint32_t eidx0,
                                           int erow) {
@@ -679,7 +691,7 @@ __device__ __forceinline__ void panel_store(const bf16_t* panel, int ops, bf16_t
 
 // softmax scale and log2(e) are folded into one fma feeding v_exp_f32; the mask multiply only exists when a mask is
 // given; one dropout hash serves two elements; all lane offsets are 32-bit.
-template <bool HAS_MASK, int PT, bool SUB>
+template <bool HAS_MASK, int PT, bool SUB, bool GATHER = false>
 __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR address math
@@ -710,7 +722,12 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
     const bf16_t* src = qkv + (size_t)t.sb * L * N3 + hoff;
     const int hcount = min(AW, a.heads - t.hg * AW);
     dead_next = SUB && a.tmask[t.sb] == 0;               // a sequence of padding tokens only: Q|K|V = bias, nothing to load
-    if (!dead_next) {
+    if (GATHER) {
+      const int32_t* idp = a.ids + (size_t)t.sb * L;
+      panel_load_g(rq, qkv, N3, idp, hoff, pc, hcount);
+      panel_load_g(rk, qkv, N3, idp, N + hoff, pc, hcount);
+      panel_load_g(rv, qkv, N3, idp, 2 * N + hoff, pc, hcount);
+    } else if (!dead_next) {
       panel_load(rq, src, N3, pc, hcount);
       panel_load(rk, src + N, N3, pc, hcount);
       panel_load(rv, src + 2 * N, N3, pc, hcount);
@@ -1349,6 +1366,7 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   auto pick = [&](auto tag_mask, auto tag_sub) {
     constexpr bool HM = decltype(tag_mask)::value, SB = decltype(tag_sub)::value;
     if (bwd) p3 ? go(bwd_kernel<HM, 3, SB>) : go(bwd_kernel<HM, 4, SB>);
+    else if (!SB && a.ids != nullptr) p3 ? go(fwd_kernel<HM, 3, false, true>) : go(fwd_kernel<HM, 4, false, true>);
     else p3 ? go(fwd_kernel<HM, 3, SB>) : go(fwd_kernel<HM, 4, SB>);
   };
   if (a.mask) sub ? pick(std::true_type{}, std::true_type{}) : pick(std::true_type{}, std::false_type{});
@@ -1397,7 +1415,7 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
                         const float* bias, const int32_t* seq_list, const int32_t* seq_count) {
   if (!nr_attn_mfma_supported(L, d_head)) return -1;
   AttnMArgs a;
-  a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr;
+  a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr; a.ids = nullptr;
   a.qkv = qkv; a.mask = mask; a.y = y; a.dy = dy; a.dqkv = dqkv;
   a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;
   a.scale = 1.0f / sqrtf((float)d_head);
@@ -1422,6 +1440,23 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   return dtype == NR_BF16 ? launch_t<bf16_t>(bwd, a, stream) : launch_t<float>(bwd, a, stream);
 }
 
+
+// Forward attention whose Q|K|V rows are gathered from a per-token-id table of projections [V, 3N] (bf16 panel kernel:
+// L <= 32, d_head % 4 == 0, 8-byte aligned).  Returns -1 when the shape has no such kernel.
+int nr_launch_attn_gather_fwd(const void* proj_table, const int32_t* ids, const float* mask, void* y, int n, int L, int heads,
+                              int d_head, const DropCfg& drop, hipStream_t stream) {
+  if (!nr_attn_pad_ok(NR_BF16, L, d_head, proj_table, y) || ids == nullptr) return -1;
+  AttnMArgs a;
+  a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr;
+  a.ids = ids;
+  a.qkv = proj_table; a.mask = mask; a.y = y; a.dy = nullptr; a.dqkv = nullptr;
+  a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;
+  a.scale = 1.0f / sqrtf((float)d_head);
+  a.drop = drop;
+  a.vec = 1;
+  NrProfScope ps(stream, "attn_mfma_fwd_gather[bf16,n=%d,L=%d,h=%d,d=%d]", n, L, heads, d_head);
+  return b16::launch(false, a, stream);
+}
 
 // Fused title-level forward (gather + dropout + Q|K|V projection + attention + dropout), bf16 only.
 // Returns -1 when the shape is outside what the fused kernel covers (the caller then runs the unfused path).

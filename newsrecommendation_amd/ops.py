@@ -99,6 +99,34 @@ def _ws(nbytes: int, device) -> torch.Tensor:
     return torch.empty((int(nbytes) + 3) // 4, dtype=torch.int32, device=device)
 
 
+# Zero-gradient hint between two adjacent backward calls: the pooling backward knows which sequences had a zero pooled
+# gradient (their dx rows are exact zeros) and leaves [n] flags in its workspace; when the VERY NEXT libnrhip backward call
+# is the producer of the pooled tensor (MHSA / conv) and receives that same dx buffer as its dy, it takes the flags
+# instead of scanning dy (0.1 ms at the bench shape).  Anything else in between drops the hint.
+_bwd_seq = 0
+_flag_hint = None
+
+
+def _enter_backward() -> int:
+    global _bwd_seq
+    _bwd_seq += 1
+    return _bwd_seq
+
+
+def _offer_flags(seq, dx, n, flags_ptr, keepalive) -> None:
+    global _flag_hint
+    _flag_hint = (seq, dx.data_ptr(), dx.numel(), n, flags_ptr, keepalive) if flags_ptr and dx is not None else None
+
+
+def _take_flags(seq, dy, n):
+    """(device pointer, keep-alive tensor) of the [n] flags for `dy`, or (0, None)."""
+    global _flag_hint
+    h, _flag_hint = _flag_hint, None
+    if h is not None and h[0] == seq - 1 and h[1] == dy.data_ptr() and h[2] == dy.numel() and h[3] == n:
+        return h[4], h[5]
+    return 0, None
+
+
 def grad_target(p):
     """The preallocated gradient view of a parameter that lives in a flat bucket (parallel.FlatBucket sets
     `_nr_grad`), or None.  Backward passes ACCUMULATE into such a view directly -- the kernels add into their dW / db /
@@ -174,6 +202,44 @@ class _TableCache:
 
 table_cache = _TableCache()
 
+# Bumped whenever parameters are rewritten behind autograd's back (parallel.FlatBucket's Adam kernel): caches derived from
+# parameter VALUES (not just from their version counters) key on it.
+param_epoch = 0
+
+
+def bump_param_epoch() -> None:
+    global param_epoch
+    param_epoch += 1
+
+
+class _ProjectedTables:
+    """Eval-mode shortcut of the title-level MHSA: without input dropout Q|K|V of a token are
+    `W_{Q|K|V} e_w + b` of its table row e_w -- a function of the token ID alone -- so the [V, d_model] table is projected
+    ONCE to [V, 3N] (one GEMM over V rows instead of one over every token occurrence: 100 000 news x 30 tokens -> 30 000
+    rows) and the attention kernel gathers projected rows.  Same GEMM kernel, same operands, same rounding as projecting each
+    occurrence: the values are identical.  Rebuilt when the table, a weight or the parameter epoch changes."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, table, params, wcat, bcat, code):
+        sig = (param_epoch, table._version, table.data_ptr()) + tuple((p._version, p.data_ptr()) for p in params)
+        ent = self._c.get(id(table))
+        if ent is None or ent[0] != sig or ent[2]() is not table:
+            tp = table_cache.get(table, code)                                  # [V, ld] packed operand
+            w_p = pack(wcat, code)                                             # [3N, ld], same zero-padded K as the table
+            if w_p.shape[1] != tp.shape[1]:
+                raise RuntimeError(f"projected table: operand leading dimensions differ ({w_p.shape[1]} vs {tp.shape[1]})")
+            proj = gemm_nt(tp, w_p, bias=bcat.detach().float().contiguous())   # [V, 3N], bias added, rounded to bf16 once
+            if id(table) not in self._c:
+                weakref.finalize(table, self._c.pop, id(table), None)
+            ent = (sig, proj, weakref.ref(table))
+            self._c[id(table)] = ent
+        return ent[1]
+
+
+projected_tables = _ProjectedTables()
+
 
 # ------------------------------------------------------------------------------------------ MHSA
 class MHSAFunction(Function):
@@ -233,6 +299,7 @@ class MHSAFunction(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        seq = _enter_backward()
         src, ids, mask_c, w_p, b_p, wcat, qkv, x_rows = ctx.saved_tensors
         cfg = ctx.cfg
         n, L, N, d_model, heads, d_head, ldx, gather = ctx.dims
@@ -240,6 +307,7 @@ class MHSAFunction(Function):
         dy = dy.contiguous()
         if dy.dtype != torch_dtype(code):
             dy = dy.to(torch_dtype(code))
+        seq_nz, seq_nz_owner = _take_flags(seq, dy, n)
         dqkv = _scratch(*qkv.shape, dtype=qkv.dtype, device=dev)
         bucket = cfg.get("flat")
         if bucket is not None:
@@ -256,7 +324,7 @@ class MHSAFunction(Function):
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
                           x_rows=ptr(x_rows), ld_rows=x_rows.shape[1] if x_rows is not None else 0,
-                          row_ws_ready=int(ws_ready))
+                          seq_nz=seq_nz, row_ws_ready=int(ws_ready))
         if need_x:
             w_t = pack(wcat, code, transpose=True)                     # [d_model, 3N]
             if gather:
@@ -276,6 +344,29 @@ class MHSAFunction(Function):
         return (gx, dw[:N], db[:N], dw[N:2 * N], db[N:2 * N], dw[2 * N:], db[2 * N:], None, None, None)
 
 
+USE_PROJECTED_TABLE = True      # eval-mode shortcut of the gather MHSA (see _ProjectedTables); off: project every occurrence
+
+
+def _mhsa_projected(table, params, flat, ids, mask, heads, code, p_out):
+    """No-grad, no input dropout, bf16, L <= 32: attention over projections gathered from the once-projected table."""
+    wq, bq, wk, bk, wv, bv = params
+    if flat is not None:
+        wcat, bcat = flat["w"], flat["b"]
+    else:
+        wcat, bcat = torch.cat([wq, wk, wv], dim=0), torch.cat([bq, bk, bv])
+    proj = projected_tables.get(table, params, wcat, bcat, code)
+    n, L = ids.shape
+    N, d_model = wq.shape
+    mask_c = mask.contiguous().float() if mask is not None else None
+    y = torch.empty(n, L, N, dtype=torch_dtype(code), device=ids.device)
+    tp = table_cache.get(table, code)
+    d = _lib.MhsaDesc(n=n, L=L, d_model=d_model, heads=heads, d_head=N // heads, dtype=code, src_kind=NR_SRC_GATHER, x=ptr(tp),
+                      ldx=tp.shape[1], ids=ptr(ids), p_in=0.0, seed_in=0, p_out=p_out, seed_out=draw_seed() if p_out > 0 else 0,
+                      mask=ptr(mask_c), w_qkv=ptr(proj), ldw=tp.shape[1], b_qkv=ptr(proj), proj_table=ptr(proj))
+    check(_lib.lib().nr_mhsa_fwd(C.byref(d), None, ptr(y), _stream()), "nr_mhsa_fwd")
+    return y
+
+
 def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int, code: int, mask=None, ids=None, table=None, p_in=0.0, p_out=0.0, flat=None):
     """Dense: x [n, L, d_model] (compute dtype).  Gather: ids int32 [n, L] + fp32 `table` parameter.
     flat: {"w": [3N, d_model], "b": [3N], "gw", "gb"} views of a flat parameter / gradient bucket (parallel.FlatBucket)."""
@@ -288,6 +379,10 @@ def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int, code: int, mask=None, ids=None, 
             ids = ids.to(torch.int32)
         if CHECK_INDICES:
             check_ids(ids, table.shape[0], "token id")
+        N = wq.shape[0]
+        if (not torch.is_grad_enabled() and p_in == 0 and code == NR_BF16 and ids.dim() == 2 and ids.shape[1] <= 32
+                and (N // heads) % 4 == 0 and N % 8 == 0 and USE_PROJECTED_TABLE):
+            return _mhsa_projected(table, (wq, bq, wk, bk, wv, bv), flat, ids.contiguous(), mask, heads, code, float(p_out))
         cfg["table_packed"] = table_cache.get(table, code)
         cfg["table_shape"] = tuple(table.shape)
         if table.requires_grad and torch.is_grad_enabled():
@@ -321,6 +416,7 @@ class SDPAFunction(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _enter_backward()
         qkv, mask_c = ctx.saved_tensors
         n, L, heads, d_head, code = ctx.dims
         dy = dy.contiguous()
@@ -381,6 +477,7 @@ class PoolFunction(Function):
 
     @staticmethod
     def backward(ctx, g):
+        seq = _enter_backward()
         x, mask_c, w1_p, b1_c, w2_c, b2_c, e, alpha, w1 = ctx.saved_tensors
         n, L, N, q = ctx.dims
         code, dev = ctx.code, g.device
@@ -402,6 +499,7 @@ class PoolFunction(Function):
         check(_lib.lib().nr_additive_pool_bwd(C.byref(d), ptr(e), ptr(alpha), ptr(g), N, ptr(w1_t),
                                               w1_t.shape[1] if w1_t is not None else 0, ptr(dpre), ptr(partial), ptr(dw1),
                                               ptr(db1), ptr(dw2), ptr(db2), ptr(dx), _stream()), "nr_additive_pool_bwd")
+        _offer_flags(seq, dx, n, _lib.lib().nr_pool_seq_flags(C.byref(d), ptr(partial)), partial)
         if direct:
             return dx, None, None, None, None, None, None
         return dx, dw1, db1, dw2.view(1, q), db2, None, None
@@ -432,6 +530,7 @@ class BlendFunction(Function):
 
     @staticmethod
     def backward(ctx, dout):
+        _enter_backward()
         (mask_c,) = ctx.saved_tensors
         n, L, N = ctx.dims
         dout = dout.contiguous()
@@ -477,6 +576,7 @@ class ScoreCEFunction(Function):
 
     @staticmethod
     def backward(ctx, gloss, gscore):
+        _enter_backward()
         cand, user, label, score = ctx.saved_tensors
         B, Cn, N = cand.shape
         gl = gloss.contiguous().float() if gloss is not None else None
@@ -527,18 +627,20 @@ class ConvFunction(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        seq = _enter_backward()
         table_p, w_p, b_c = ctx.saved_tensors
         n, T, D, Dp, N, stride = ctx.dims
         cfg, code, dev = ctx.cfg, ctx.cfg["code"], dy.device
         dy = dy.contiguous()
         if dy.dtype != torch_dtype(code):
             dy = dy.to(torch_dtype(code))
+        seq_nz, seq_nz_owner = _take_flags(seq, dy, n)
         dwp = torch.zeros(N, 3 * Dp, dtype=torch.float32, device=dev)
         direct = all(t is not None for t in ctx.targets)
         db = ctx.targets[1] if direct else torch.zeros(N, dtype=torch.float32, device=dev)
         d = _lib.ConvDesc(n=n, T=T, D=D, Dp=Dp, N=N, dtype=code, table=ptr(table_p), ids=ctx.ids.data_ptr(), ids_stride=stride,
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], w_pack=ptr(w_p), bias=ptr(b_c), x_rows=ptr(ctx.x_rows),
-                          ld_rows=3 * Dp)
+                          ld_rows=3 * Dp, seq_nz=seq_nz)
         bwd_ws = _ws(_lib.lib().nr_conv_workspace_bytes(C.byref(d)), dev) if ctx.x_rows is not None else None
         d.bwd_ws, d.bwd_ws_bytes = ptr(bwd_ws), (bwd_ws.numel() * 4 if bwd_ws is not None else 0)
         check(_lib.lib().nr_conv1d_k3_bwd(C.byref(d), ptr(dy), ptr(dwp), ptr(db), _stream()), "nr_conv1d_k3_bwd")
@@ -583,6 +685,7 @@ class GatherLinearFunction(Function):
 
     @staticmethod
     def backward(ctx, dout):
+        _enter_backward()
         emb_p, w_p, b_c, w = ctx.saved_tensors
         M, K, N, stride, emb_shape = ctx.dims
         code, dev = ctx.code, dout.device

@@ -138,8 +138,12 @@ class FlatBucket:
         self._params_changed()
 
     def _params_changed(self):
+        """The kernels wrote the parameters behind autograd's back (no version bump): packed compute-dtype copies of the
+        bucket's OWN tables must be rebuilt.  Frozen tables (e.g. NAML's 2.3 GB title table) are not touched."""
         from . import ops
-        ops.table_cache.invalidate()                 # packed bf16 copies of embedding tables follow the fp32 master
+        for p in self.params:
+            ops.table_cache.invalidate(p)
+        ops.bump_param_epoch()
 
     def zero_grad(self):
         self.grad.zero_()

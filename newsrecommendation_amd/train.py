@@ -188,6 +188,7 @@ def encode_news(model, news_combined, batch_size, device, shard_over_ranks=False
     the reference encodes the whole corpus on every rank."""
     ids = torch.as_tensor(np.asarray(news_combined), dtype=torch.int32)
     n = ids.shape[0]
+    batch_size = max(int(batch_size), 16384)                   # the encoder is row-wise: bigger chunks, same vectors, fewer launches
     world = parallel.world_size() if shard_over_ranks else 1
     rank = dist.get_rank() if world > 1 else 0
     per = (n + world - 1) // world

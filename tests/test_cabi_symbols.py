@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "nrhip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|size_t)\s+(nr_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|size_t|const int32_t\*)\s+(nr_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_header_matches_binding_table():

@@ -116,3 +116,32 @@ def test_index_validation_raises_like_torch():
             m(hist, mask, cand, torch.tensor([0, 2]).cuda())
     finally:
         ops.CHECK_INDICES = False
+
+
+def test_eval_projected_table_shortcut_gives_the_same_news_vectors():
+    """Eval mode, bf16: attention over projections gathered from the once-projected word table (ops._ProjectedTables) vs
+    projecting every token occurrence -- same GEMM kernel and rounding, so the news vectors agree to bf16 output rounding;
+    and the shortcut follows parameter updates (version counters / parameter epoch)."""
+    import bench
+    from newsrecommendation_amd.model import NRMS
+    args = bench.make_args("bf16")
+    g = torch.Generator().manual_seed(1)
+    table = torch.randn(3000, 300, generator=g) * 0.4
+    table[0] = 0
+    torch.manual_seed(0)
+    m = NRMS.Model(args, table.numpy()).cuda().eval()
+    ids = bench.synth_news_table(args, 2000, 3000, 3).cuda()
+    with torch.no_grad():
+        ops.USE_PROJECTED_TABLE = False
+        ref = m.news_encoder(ids)
+        ops.USE_PROJECTED_TABLE = True
+        got = m.news_encoder(ids)
+        assert float((got - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), float((got - ref).abs().max())
+        # a parameter update must invalidate the projected table
+        m.news_encoder.multi_head_self_attn.W_Q.weight.mul_(1.5)
+        got2 = m.news_encoder(ids)
+        ops.USE_PROJECTED_TABLE = False
+        ref2 = m.news_encoder(ids)
+        ops.USE_PROJECTED_TABLE = True
+    assert float((ref2 - ref).abs().max()) > 2e-3                      # the update is visible ...
+    assert float((got2 - ref2).abs().max()) <= 2e-3 * float(ref2.abs().max())   # ... and the shortcut followed it
