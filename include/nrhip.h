@@ -129,6 +129,9 @@ typedef struct {
   const void* proj_table; /* nr_mhsa_fwd only, optional [V, 3N] dtype = table . W_qkv^T + b_qkv (one nr_gemm_nt over the table):
                          eval mode (p_in == 0, bf16 gather source, qkv == NULL, no backward) gathers the projections of a token
                          from here instead of projecting every occurrence -- same values, ~V/(n*L) of the GEMM work */
+  const int32_t* seq_needed; /* nr_mhsa_fwd only, optional [n]: 0 = the caller will not use this sequence's output (it reaches the
+                         loss through a factor 0, e.g. a masked history slot, src/model/NRMS.py:59-60, model_utils.py:28,51): its y rows
+                         are written as exact zeros without being computed.  NULL: every sequence is computed.              */
   const int32_t* seq_nz; /* nr_mhsa_bwd only, optional [n]: 0 = the upstream gradient dy of this sequence is exactly zero (the flags
                          nr_additive_pool_bwd leaves in its workspace, see nr_pool_seq_flags); NULL: the library scans dy itself */
   int row_ws_ready;   /* nr_mhsa_bwd only: nonzero = row_ws still holds what nr_mhsa_fwd wrote for these ids (reused as is).
@@ -212,6 +215,10 @@ typedef struct {
   const float* w2;   /* [q] (att_fc2.weight [1, q]) */
   const float* b2;   /* [1] */
   size_t partial_bytes; /* nr_additive_pool_bwd: size of `partial` in bytes, >= nr_pool_workspace_bytes(d) (checked) */
+  const int32_t* seq_needed; /* optional [n]: 0 = this sequence's output is not used by the caller.  nr_additive_pool_fwd writes its
+                         out row and alpha as zeros and may leave its e rows unwritten; nr_additive_pool_bwd must be given the same
+                         flags: the pooled gradient of such a sequence is zero by contract, its dpre / dx rows are written as zeros
+                         and its e rows are never read                                                                       */
 } nr_pool_desc;
 /* Bytes of the `partial` workspace of nr_additive_pool_bwd. */
 size_t nr_pool_workspace_bytes(const nr_pool_desc* d);

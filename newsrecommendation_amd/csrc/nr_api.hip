@@ -9,12 +9,14 @@
 // launchers defined in nr_attn.hip / nr_pool.hip
 int nr_launch_attn(bool bwd, int dtype, const void* qkv, const float* mask, void* y, const void* dy, void* dqkv, int n, int L,
                    int heads, int d_head, const DropCfg& drop, hipStream_t stream, const uint32_t* tmask = nullptr,
-                   const float* bias = nullptr, const int32_t* seq_list = nullptr, const int32_t* seq_count = nullptr);
+                   const float* bias = nullptr, const int32_t* seq_list = nullptr, const int32_t* seq_count = nullptr,
+                   const int32_t* needed = nullptr);
 bool nr_attn_pad_ok(int dtype, int L, int d_head, const void* p0, const void* p1);
 int nr_launch_attn_gather_fwd(const void* proj_table, const int32_t* ids, const float* mask, void* y, int n, int L, int heads,
                               int d_head, const DropCfg& drop, hipStream_t stream);
 int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
-                            float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s);
+                            float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s,
+                            const int32_t* needed = nullptr);
 int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float* w2, const float* alpha, const float* g,
                             int ld_g, void* dpre, float* partial, float* dw2, float* db2, int n, int L, int N, int q,
                             hipStream_t s, const int32_t* seq_nz = nullptr);
@@ -39,7 +41,7 @@ struct OptDef { const char* name; int def; };
 const OptDef g_opt_defs[NR_OPT_COUNT] = {
     {"NO_SLABS", 0},   {"NO_ATTN_SKIP", 0}, {"SIDE_STREAM", 0}, {"ATTN_OLD", 0},  {"ATTN_VALU", 0},   {"NO_PAD_SUB", 0},
     {"NO_FUSED_FWD", 0}, {"NO_TN3", 0},     {"TN_V1", 0},       {"TN3_ROUNDS", 0}, {"TN3_WK", 0},      {"TN3_NI", 0},
-    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}};
+    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}};
 std::atomic<int> g_opt[NR_OPT_COUNT];
 std::once_flag g_opt_once;
 void opt_init() {
@@ -482,7 +484,7 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   }
   if ((rc = nr_launch_gemm_nt(d->dtype, A, d->w_qkv, d->ldw, M, 3 * N, Kp, EPI_STORE, ep, s))) return rc;
   return nr_launch_attn(false, d->dtype, qkv, d->mask, y, nullptr, nullptr, d->n, d->L, d->heads, d->d_head,
-                        nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr);
+                        nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr, nullptr, nullptr, d->seq_needed);
 }
 
 int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dqkv, const void* w_qkv_t, int ldwt,
@@ -673,8 +675,9 @@ int nr_additive_pool_fwd(const nr_pool_desc* d, void* e, float* alpha, float* ou
   hipStream_t s = (hipStream_t)stream;
   RowSrc A = dense_rows(d->x, d->N, d->N);
   EpiArgs ep = store_epi(e, d->q, d->dtype, d->b1, 1);
+  ep.seq_nz = d->seq_needed; ep.L = d->L;          // row tiles made of unneeded sequences only are not computed (e stays unwritten)
   if ((rc = nr_launch_gemm_nt(d->dtype, A, d->w1, d->ldw1, d->n * d->L, d->q, d->N, EPI_STORE, ep, s))) return rc;
-  return nr_launch_pool_core_fwd(d->dtype, d->x, e, d->w2, d->b2, d->mask, alpha, out, ld_out, d->n, d->L, d->N, d->q, s);
+  return nr_launch_pool_core_fwd(d->dtype, d->x, e, d->w2, d->b2, d->mask, alpha, out, ld_out, d->n, d->L, d->N, d->q, s, d->seq_needed);
 }
 
 int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alpha, const float* g, int ld_g, const void* w1_t,
@@ -699,7 +702,10 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
     ws = reinterpret_cast<int32_t*>(partial + pool_ws_used(d->n, d->q));   // the int scratch behind the partial rows
     if ((rc = nr_launch_row_flags_f32(g, ld_g, d->N, d->n, ws, s))) return rc;
   }
-  if ((rc = nr_launch_pool_core_bwd(d->dtype, d->x, e, d->w2, alpha, g, ld_g, dpre, partial, dw2, db2, d->n, d->L, d->N, d->q, s, ws)))
+  // Without the flags derived from g (small / fp32 shapes) the caller's "output not needed" flags serve: such a sequence has a
+  // zero pooled gradient by contract, and its e rows may never have been written by the forward.
+  const int32_t* zero_flags = ws != nullptr ? ws : d->seq_needed;
+  if ((rc = nr_launch_pool_core_bwd(d->dtype, d->x, e, d->w2, alpha, g, ld_g, dpre, partial, dw2, db2, d->n, d->L, d->N, d->q, s, zero_flags)))
     return rc;
   RowSrc X = dense_rows(d->x, d->N, d->N);
   const bool fork = dx != nullptr && side_enabled() && M >= 65536;
@@ -717,7 +723,7 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
     RowSrc P = dense_rows(dpre, d->q, d->q);
     EpiArgs ep = store_epi(dx, d->N, d->dtype, nullptr, 0);
     ep.rowscale = alpha; ep.G = g; ep.ldg = ld_g; ep.L = d->L;
-    ep.seq_nz = ws;                                  // tiles made of zero-gradient sequences only just write zeros
+    ep.seq_nz = zero_flags;                          // tiles made of zero-gradient sequences only just write zeros
     rc = nr_launch_gemm_nt(d->dtype, P, w1_t, ldw1t, M, d->N, d->q, EPI_POOLBWD, ep, s2);
   }
   if (fork) {

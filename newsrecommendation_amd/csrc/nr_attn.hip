@@ -240,19 +240,19 @@ int launch_attn_d(bool bwd, int DH, const AttnArgs& a, hipStream_t s) {
 bool nr_attn_mfma_supported(int L, int d_head);
 int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask, void* y, const void* dy, void* dqkv, int n,
                         int L, int heads, int d_head, const DropCfg& drop, hipStream_t stream, const uint32_t* tmask,
-                        const float* bias, const int32_t* seq_list, const int32_t* seq_count);
+                        const float* bias, const int32_t* seq_list, const int32_t* seq_count, const int32_t* needed);
 
 // qkv [n*L, 3N] -> y [n*L, N] (fwd) ; (qkv, dy) -> dqkv (bwd)
 int nr_launch_attn(bool bwd, int dtype, const void* qkv, const float* mask, void* y, const void* dy, void* dqkv, int n, int L,
                    int heads, int d_head, const DropCfg& drop, hipStream_t stream, const uint32_t* tmask, const float* bias,
-                   const int32_t* seq_list, const int32_t* seq_count) {
+                   const int32_t* seq_list, const int32_t* seq_count, const int32_t* needed) {
   NR_CHECK_ARG(L >= 1 && L <= 64, "attention: L=%d must be in [1, 64]", L);
   NR_CHECK_ARG(n >= 1 && heads >= 1, "attention: empty problem");
   // L <= 32: one wave per (sequence, head) on the matrix cores; longer sequences: LDS/VALU kernels below.
   const bool force_valu = nr_opt(NR_OPT_ATTN_VALU) != 0;
   if (!force_valu && nr_attn_mfma_supported(L, d_head)) {
     const int rc = nr_launch_attn_mfma(bwd, dtype, qkv, mask, y, dy, dqkv, n, L, heads, d_head, drop, stream, tmask, bias, seq_list,
-                                       seq_count);
+                                       seq_count, needed);
     if (rc >= 0) return rc;   // -1: this shape / dtype has no MFMA kernel, use the LDS/VALU kernels below
   }
   NR_CHECK_ARG(tmask == nullptr, "attention: padding-token substitution is not available on the LDS/VALU kernels");

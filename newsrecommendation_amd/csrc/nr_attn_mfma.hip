@@ -41,6 +41,7 @@ struct AttnMArgs {
   const int32_t* seq_count;  //   out have exactly zero dQ|dK|dV rows that nothing downstream reads
   const uint32_t* tmask;  // optional [n]: live-token bit mask of each sequence.  0 = padding tokens only: every Q|K|V row
   const float* bias;      //   of that sequence is this bias [3N]; its qkv rows are never written and never read
+  const int32_t* needed;  // optional (forward, bf16 panel kernel) [n]: 0 = nobody uses this sequence's output: zeros are stored
   const int32_t* ids;     // optional (forward, bf16 panel kernel) [n*L]: row m of Q|K|V is qkv[ids[m]] -- `qkv` is then a
                           //   per-token-id table of projections (eval mode: W x + b depends on the token id only)
 };
@@ -589,13 +590,27 @@ template <int PT> struct Pieces {
   __device__ __forceinline__ int loff(int t) const { return lq[t] & 0xffff; }
   __device__ __forceinline__ int q4(int t) const { return lq[t] >> 16; }
 };
-template <int PT> __device__ __forceinline__ Pieces<PT> make_pieces(int tid, int L, int d, int nimg) {
+// A wave-uniform 32-bit word through the scalar data cache: s_load + lgkmcnt instead of a vector load + vmcnt(0), which
+// would also wait for every store the wave still has in flight (loads and stores share vmcnt on gfx9).  Only for data
+// written by EARLIER kernels (the scalar cache is not coherent with this kernel's own vector stores).
+__device__ __forceinline__ uint32_t sload_u32(const void* p) {
+  uint32_t v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
+// FULL: every head slot of a group is a real head (heads % AW == 0).  The slots beyond the L*AW*d/4 pieces of a panel then
+// WRAP onto real pieces (duplicates load / store the same bytes), so every thread issues the same number of memory
+// instructions per item and the compiler can count them (s_waitcnt vmcnt(N) instead of vmcnt(0)).
+template <int PT, bool FULL = false> __device__ __forceinline__ Pieces<PT> make_pieces(int tid, int L, int d, int nimg) {
   Pieces<PT> pc;
   const int pph = d >> 2, ppr = AW * pph;            // pieces per head row / per panel row
   const uint32_t inv_ppr = (65536 + ppr - 1) / ppr, inv_pph = (65536 + pph - 1) / pph;   // exact for p < 1024, divisors <= 40
+  const int npieces = L * ppr;
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
-    const int p = tid + t * AW * 64;
+    int p = tid + t * AW * 64;
+    if (FULL) p %= npieces;                            // once per thread
     const int row = (int)(((uint32_t)p * inv_ppr) >> 16), q = p - row * ppr;
     const int h = (int)(((uint32_t)q * inv_pph) >> 16), c = 4 * (q - h * pph);
     const bool ok = row < L;
@@ -614,6 +629,18 @@ __device__ __forceinline__ void panel_load(Panel<PT>& r, const bf16_t* __restric
     if (pc.hh(t) < hcount) r.v[t] = *reinterpret_cast<const bf16x4*>(src + (uint32_t)(pc.row(t) * ld + pc.q4(t)));
   }
 }
+// FULL variants: no predicates (see make_pieces)
+template <int PT>
+__device__ __forceinline__ void panel_load_all(Panel<PT>& r, const bf16_t* __restrict__ src, int ld, const Pieces<PT>& pc) {
+#pragma unroll
+  for (int t = 0; t < PT; ++t) r.v[t] = *reinterpret_cast<const bf16x4*>(src + (uint32_t)(pc.row(t) * ld + pc.q4(t)));
+}
+template <int PT>
+__device__ __forceinline__ void panel_store_all(const bf16_t* panel, int ops, bf16_t* __restrict__ dst, int ld, const Pieces<PT>& pc) {
+#pragma unroll
+  for (int t = 0; t < PT; ++t)
+    *reinterpret_cast<bf16x4*>(dst + (uint32_t)(pc.row(t) * ld + pc.q4(t))) = *reinterpret_cast<const bf16x4*>(panel + pc.row(t) * ops + pc.q4(t));
+}
 // row-indirect variant: token row r of the sequence lives at table row ids[r] (ids points at the sequence's first token)
 template <int PT>
 __device__ __forceinline__ void panel_load_g(Panel<PT>& r, const bf16_t* __restrict__ table, int ld, const int32_t* __restrict__ ids,
@@ -624,12 +651,12 @@ __device__ __forceinline__ void panel_load_g(Panel<PT>& r, const bf16_t* __restr
     if (pc.hh(t) < hcount) r.v[t] = *reinterpret_cast<const bf16x4*>(table + (size_t)ids[pc.row(t)] * ld + coff + pc.q4(t));
   }
 }
-template <bool DROP, int PT>
+template <bool DROP, int PT, bool FULL = false>
 __device__ __forceinline__ void panel_put(const Panel<PT>& r, bf16_t* img0, const Pieces<PT>& pc, const DropCfg& drop, uint32_t eidx0,
                                           int erow) {
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
-    if (pc.hh(t) < AW) {
+    if (FULL || pc.hh(t) < AW) {
       bf16x4 v = r.v[t];
       if (DROP && drop.thresh) {
         const uint32_t kb = nr_keep4(drop.key, eidx0 + (uint32_t)(pc.row(t) * erow + pc.q4(t)), drop.thresh);
@@ -641,13 +668,13 @@ __device__ __forceinline__ void panel_put(const Panel<PT>& r, bf16_t* img0, cons
   }
 }
 // Q / K / V images of a sequence made of padding tokens only: every row is the bias (table in LDS), nothing was loaded
-template <int PT>
+template <int PT, bool FULL = false>
 __device__ __forceinline__ void panel_put_bias(bf16_t* img0, const Pieces<PT>& pc, const bf16_t* sbias, int hcount) {
 #pragma unroll
   for (int t = 0; t < PT; ++t) {
-    if (pc.hh(t) < AW) {
+    if (FULL || pc.hh(t) < AW) {
       bf16x4 v = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
-      if (pc.hh(t) < hcount) v = *reinterpret_cast<const bf16x4*>(sbias + pc.q4(t));
+      if (FULL || pc.hh(t) < hcount) v = *reinterpret_cast<const bf16x4*>(sbias + pc.q4(t));
       *reinterpret_cast<bf16x4*>(img0 + pc.loff(t)) = v;
     }
   }
@@ -691,7 +718,11 @@ __device__ __forceinline__ void panel_store(const bf16_t* panel, int ops, bf16_t
 
 // softmax scale and log2(e) are folded into one fma feeding v_exp_f32; the mask multiply only exists when a mask is
 // given; one dropout hash serves two elements; all lane offsets are 32-bit.
-template <bool HAS_MASK, int PT, bool SUB, bool GATHER = false>
+// LC / DC / HC: compile-time sequence length, head width and head count (0 = taken from the arguments).  The title-level
+// shape of the reference's defaults (30 tokens, 20 heads of 20) is instantiated with constants: both kernels are bound by
+// instruction issue (~420 / ~560 VALU instructions per item and wave around 4 / 14 MFMAs), and constants fold the row /
+// column predicates and the address arithmetic.
+template <bool HAS_MASK, int PT, bool SUB, bool GATHER = false, bool FULL = false, int LC = 0, int DC = 0, int HC = 0>
 __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR address math
@@ -702,10 +733,11 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   bf16_t* sOut = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(img0 + (size_t)AW * 3 * IMG) + AW * 32);   // [32][ops]
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
   bf16_t* y = reinterpret_cast<bf16_t*>(a.y);
-  const int N = a.N, L = a.L, d = a.d, N3 = 3 * a.N, ops = AW * a.d + 8;
+  const int L = LC ? LC : a.L, d = DC ? DC : a.d, heads = HC ? HC : a.heads;
+  const int N = heads * d, N3 = 3 * N, ops = AW * d + 8;
   const int h2 = lane >> 5;
   const float c1 = a.scale * LOG2E;   // scale > 0: the row maximum can be taken on the raw scores
-  const Pieces<PT> pc = make_pieces<PT>(tid, L, d, 3);
+  const Pieces<PT> pc = make_pieces<PT, FULL>(tid, L, d, 3);
   zero_images(img0, AW * 3, tid);
   bf16_t* sBias = sOut + 32 * ops;                     // SUB: bias [3N] as bf16 (what the projection of a zero row is)
   if (SUB)
@@ -713,21 +745,37 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
 
   // One workgroup walks ALL heads of a sequence (AW heads at a time) before moving on; the panels of the NEXT item
   // are loaded into registers while the current item is computed.
-  const int hgroups = (a.heads + AW - 1) / AW, stride = gridDim.x;
+  // FULL: every thread issues the same loads / stores for every item (duplicate pieces, dead sequences read sequence 0's
+  // rows and ignore them), the per-sequence flag comes through the scalar cache -- nothing in the loop waits on vmcnt(0),
+  // so the stores of item i drain while item i+1 is computed.
+  const int hgroups = (heads + AW - 1) / AW, stride = gridDim.x;
   ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};   // blockIdx.x < n by launch
   Panel<PT> rq, rk, rv;
   bool dead_next = false;                                // the item sitting in rq / rk / rv is all padding
+  bool dead_seq = false;                                 // ... of the sequence the prefetcher is in
+  const bool has_needed = a.needed != nullptr;
+  bool skip_seq = false, skip_next = false, skip_cur = false;   // nobody uses the sequence's output: zeros are stored, nothing is computed
   auto prefetch = [&](const ItemIter& t) {
     const int hoff = t.hg * AW * d;
-    const bf16_t* src = qkv + (size_t)t.sb * L * N3 + hoff;
-    const int hcount = min(AW, a.heads - t.hg * AW);
-    dead_next = SUB && a.tmask[t.sb] == 0;               // a sequence of padding tokens only: Q|K|V = bias, nothing to load
+    const int hcount = min(AW, heads - t.hg * AW);
+    if (SUB && (t.hg == 0 || !FULL))                     // a sequence of padding tokens only: Q|K|V = bias, nothing to load
+      dead_seq = (FULL ? sload_u32(a.tmask + __builtin_amdgcn_readfirstlane(t.sb)) : a.tmask[t.sb]) == 0;
+    if (has_needed && (t.hg == 0 || !FULL))
+      skip_seq = (FULL ? sload_u32(a.needed + __builtin_amdgcn_readfirstlane(t.sb)) : (uint32_t)a.needed[t.sb]) == 0;
+    skip_next = has_needed && skip_seq;
+    dead_next = (SUB && dead_seq) || (FULL && skip_next);   // FULL: a skipped sequence loads like a dead one (rows ignored)
     if (GATHER) {
       const int32_t* idp = a.ids + (size_t)t.sb * L;
       panel_load_g(rq, qkv, N3, idp, hoff, pc, hcount);
       panel_load_g(rk, qkv, N3, idp, N + hoff, pc, hcount);
       panel_load_g(rv, qkv, N3, idp, 2 * N + hoff, pc, hcount);
+    } else if (FULL) {
+      const bf16_t* src = qkv + (dead_next ? (size_t)0 : (size_t)t.sb * L * N3) + hoff;   // dead: any valid rows (L2 hits), ignored
+      panel_load_all(rq, src, N3, pc);
+      panel_load_all(rk, src + N, N3, pc);
+      panel_load_all(rv, src + 2 * N, N3, pc);
     } else if (!dead_next) {
+      const bf16_t* src = qkv + (size_t)t.sb * L * N3 + hoff;
       panel_load(rq, src, N3, pc, hcount);
       panel_load(rk, src + N, N3, pc, hcount);
       panel_load(rv, src + 2 * N, N3, pc, hcount);
@@ -735,63 +783,79 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   };
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
+  // put: the item sitting in the prefetch registers goes into the LDS images (waits for its loads)
+  auto put = [&](const ItemIter& t) {
+    if (SUB && dead_next) {
+      const int hoff = t.hg * AW * d, hcount = min(AW, heads - t.hg * AW);
+      panel_put_bias<PT, FULL>(img0, pc, sBias + hoff, hcount);
+      panel_put_bias<PT, FULL>(img0 + IMG, pc, sBias + N + hoff, hcount);
+      panel_put_bias<PT, FULL>(img0 + 2 * IMG, pc, sBias + 2 * N + hoff, hcount);
+    } else {
+      panel_put<false, PT, FULL>(rq, img0, pc, nodrop, 0, 0);
+      panel_put<false, PT, FULL>(rk, img0 + IMG, pc, nodrop, 0, 0);
+      panel_put<false, PT, FULL>(rv, img0 + 2 * IMG, pc, nodrop, 0, 0);
+    }
+    if (HAS_MASK && lane < 32) sMask[lane] = (lane < L && t.hg * AW + wid < heads) ? a.mask[(size_t)t.sb * L + lane] : 0.f;
+    skip_cur = skip_next;
+  };
   __syncthreads();                                       // images zeroed, bias table in LDS
   prefetch(nx);
+  put(nx);
+  __syncthreads();
+  // Rotated software pipeline: [issue the loads of item i+1] [compute item i] [store item i] [item i+1 -> LDS].  The loads
+  // are older than the stores in the in-order vmcnt queue and both sit in one straight-line stretch of the loop body, so
+  // the wait before the LDS writes is a COUNTED one (vmcnt = number of stores): the stores of item i drain while item i+1
+  // is computed instead of stalling the wave at the top of the next iteration.
   for (; it.sb < a.n; it.next(hgroups, stride)) {
     const int head = it.hg * AW + wid;
-    const bool active = head < a.heads;
+    const bool active = head < heads;
     const size_t row0 = (size_t)it.sb * L;
     const int Ls = active ? L : 0;                       // inactive waves store nothing
-    if (SUB && dead_next) {
-      const int hoff = it.hg * AW * d, hcount = min(AW, a.heads - it.hg * AW);
-      panel_put_bias(img0, pc, sBias + hoff, hcount);
-      panel_put_bias(img0 + IMG, pc, sBias + N + hoff, hcount);
-      panel_put_bias(img0 + 2 * IMG, pc, sBias + 2 * N + hoff, hcount);
-    } else {
-      panel_put<false>(rq, img0, pc, nodrop, 0, 0);
-      panel_put<false>(rk, img0 + IMG, pc, nodrop, 0, 0);
-      panel_put<false>(rv, img0 + 2 * IMG, pc, nodrop, 0, 0);
-    }
-    if (HAS_MASK && lane < 32) sMask[lane] = (lane < Ls) ? a.mask[row0 + lane] : 0.f;
-    __syncthreads();
     nx.next(hgroups, stride);
-    if (nx.sb < a.n) prefetch(nx);
-    f32x16 st;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = 0.f;
-    mm_rr(st, sK, sQ, lane);  // S^T[j][i] (unscaled)
-    float m = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (rowof(r, h2) < L) m = fmaxf(m, st[r]);
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const float mc = m * c1;
-    float sum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = rowof(r, h2);
-      float e = (j < L) ? __builtin_amdgcn_exp2f(fmaf(st[r], c1, -mc)) : 0.f;
-      if (HAS_MASK) e *= sMask[j];
-      st[r] = e;
-      sum += e;
-    }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / (sum + 1e-8f * __builtin_amdgcn_exp2f(-mc));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] *= inv;
+    const ItemIter pf = nx.sb < a.n ? nx : it;           // the last item loads itself again: same instruction stream everywhere
+    prefetch(pf);
     f32x16 ctx;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
-    mm_xt_T(ctx, st, sV, lane);  // ctx^T[c][i]
+    if (!skip_cur) {                                     // wave-uniform
+      f32x16 st;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      mm_rr(st, sK, sQ, lane);  // S^T[j][i] (unscaled)
+      float m = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (rowof(r, h2) < L) m = fmaxf(m, st[r]);
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      const float mc = m * c1;
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = rowof(r, h2);
+        float e = (j < L) ? __builtin_amdgcn_exp2f(fmaf(st[r], c1, -mc)) : 0.f;
+        if (HAS_MASK) e *= sMask[j];
+        st[r] = e;
+        sum += e;
+      }
+      sum += __shfl_xor(sum, 32, 64);
+      const float inv = 1.f / (sum + 1e-8f * __builtin_amdgcn_exp2f(-mc));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] *= inv;
+      mm_xt_T(ctx, st, sV, lane);  // ctx^T[c][i]
+    }
     const uint32_t e0 = (uint32_t)(row0 * N) + (uint32_t)((active ? head : 0) * d);
-    acc_t_to_panel<true>(ctx, sOut, ops, wid, Ls, d, lane, a.drop, e0, (uint32_t)N);
+    if (skip_cur) acc_t_to_panel<false>(ctx, sOut, ops, wid, Ls, d, lane, nodrop, 0, 0);   // zeros, no dropout hashing
+    else acc_t_to_panel<true>(ctx, sOut, ops, wid, Ls, d, lane, a.drop, e0, (uint32_t)N);
     __syncthreads();   // output panel complete; every wave is done with its images
-    panel_store<PT>(sOut, ops, y + row0 * N + it.hg * AW * d, N, pc, min(AW, a.heads - it.hg * AW));
+    if (FULL) panel_store_all<PT>(sOut, ops, y + row0 * N + it.hg * AW * d, N, pc);
+    else panel_store<PT>(sOut, ops, y + row0 * N + it.hg * AW * d, N, pc, min(AW, heads - it.hg * AW));
+    put(pf);           // next item -> images
+    __syncthreads();   // images complete; every wave has read the output panel
   }
 }
 
-template <bool HAS_MASK, int PT, bool SUB>
-__global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void bwd_kernel(AttnMArgs a) {
+template <bool HAS_MASK, int PT, bool SUB, bool FULL = false, int LC = 0, int DC = 0, int HC = 0>
+__global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void bwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR address math
   // Image block, MATRIX-major: [Q x AW waves | V x AW | K x AW | G x AW].  The output panels of an item are written over
@@ -803,64 +867,93 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
   bf16_t *sQ = imQ + wid * IMG, *sK = imK + wid * IMG, *sV = imV + wid * IMG, *sG = imG + wid * IMG;
   float* sF = reinterpret_cast<float*>(img0 + (size_t)AW * 4 * IMG) + wid * 128;
   float *sMask = sF, *sM = sF + 32, *sInv = sF + 64, *sRd = sF + 96;
-  const int N = a.N, L = a.L, d = a.d, N3 = 3 * a.N;
+  const int L = LC ? LC : a.L, d = DC ? DC : a.d, heads = HC ? HC : a.heads;
+  const int N = heads * d, N3 = 3 * N;
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
   const bf16_t* dy = reinterpret_cast<const bf16_t*>(a.dy);
   bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.dqkv);
   const int h2 = lane >> 5, li = lane & 31;
   const float c1 = a.scale * LOG2E;
-  const Pieces<PT> pc = make_pieces<PT>(tid, L, d, 1);    // per matrix the AW head images are adjacent
+  const Pieces<PT> pc = make_pieces<PT, FULL>(tid, L, d, 1);    // per matrix the AW head images are adjacent
   zero_images(img0, AW * 4, tid);
   bf16_t* sBias = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(img0 + (size_t)AW * 4 * IMG) + AW * 128);   // SUB: bias [3N] as bf16
   if (SUB)
     for (int i = tid; i < N3; i += AW * 64) sBias[i] = (bf16_t)a.bias[i];
 
-  const int hgroups = (a.heads + AW - 1) / AW, stride = gridDim.x;
+  const int hgroups = (heads + AW - 1) / AW, stride = gridDim.x;
   ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};
   Panel<PT> rq, rk, rv, rg;
   bool dead_next = false;
   const bool listed = SUB && a.seq_list != nullptr;
   const int nseq = listed ? *a.seq_count : a.n;          // sequences to walk
   int sq_next = 0;                                       // the sequence sitting in the prefetch registers
+  // FULL (see fwd_kernel): the sequence number and its padding flag come through the scalar cache once per sequence, every
+  // thread issues the same 4 * PT loads and 3 * PT stores per item, so no wait in the loop is a vmcnt(0)
+  bool dead_seq = false;
   auto prefetch = [&](const ItemIter& t) {
-    const int sq = listed ? a.seq_list[t.sb] : t.sb;
-    sq_next = sq;
+    if (FULL) {
+      if (t.hg == 0) {
+        const int sbu = __builtin_amdgcn_readfirstlane(t.sb);
+        sq_next = listed ? (int)sload_u32(a.seq_list + sbu) : sbu;
+        if (SUB) dead_seq = sload_u32(a.tmask + sq_next) == 0;
+      }
+    } else {
+      sq_next = listed ? a.seq_list[t.sb] : t.sb;
+      dead_seq = SUB && a.tmask[sq_next] == 0;
+    }
+    const int sq = sq_next;
     const size_t r0 = (size_t)sq * L;
     const int hd = t.hg * AW * d;
-    const bf16_t* src = qkv + r0 * N3 + hd;
-    const int hcount = min(AW, a.heads - t.hg * AW);
-    dead_next = SUB && a.tmask[sq] == 0;
-    if (!dead_next) {
-      panel_load(rq, src, N3, pc, hcount);
-      panel_load(rk, src + N, N3, pc, hcount);
-      panel_load(rv, src + 2 * N, N3, pc, hcount);
+    const int hcount = min(AW, heads - t.hg * AW);
+    dead_next = SUB && dead_seq;
+    if (FULL) {
+      const bf16_t* src = qkv + (dead_next ? (size_t)0 : r0 * N3) + hd;   // dead: any valid rows (L2 hits), ignored
+      panel_load_all(rq, src, N3, pc);
+      panel_load_all(rk, src + N, N3, pc);
+      panel_load_all(rv, src + 2 * N, N3, pc);
+      panel_load_all(rg, dy + r0 * N + hd, N, pc);
+    } else {
+      const bf16_t* src = qkv + r0 * N3 + hd;
+      if (!dead_next) {
+        panel_load(rq, src, N3, pc, hcount);
+        panel_load(rk, src + N, N3, pc, hcount);
+        panel_load(rv, src + 2 * N, N3, pc, hcount);
+      }
+      panel_load(rg, dy + r0 * N + hd, N, pc, hcount);      // the upstream gradient has no padding rows
     }
-    panel_load(rg, dy + r0 * N + hd, N, pc, hcount);      // the upstream gradient has no padding rows
   };
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
+  // put: the item sitting in the prefetch registers (sequence sq_next) goes into the LDS images
+  auto put = [&](const ItemIter& t) {
+    const size_t r0 = (size_t)sq_next * L;
+    if (SUB && dead_next) {
+      const int hoff = t.hg * AW * d, hcount = min(AW, heads - t.hg * AW);
+      panel_put_bias<PT, FULL>(imQ, pc, sBias + hoff, hcount);
+      panel_put_bias<PT, FULL>(imK, pc, sBias + N + hoff, hcount);
+      panel_put_bias<PT, FULL>(imV, pc, sBias + 2 * N + hoff, hcount);
+    } else {
+      panel_put<false, PT, FULL>(rq, imQ, pc, nodrop, 0, 0);
+      panel_put<false, PT, FULL>(rk, imK, pc, nodrop, 0, 0);
+      panel_put<false, PT, FULL>(rv, imV, pc, nodrop, 0, 0);
+    }
+    panel_put<true, PT, FULL>(rg, imG, pc, a.drop, (uint32_t)(r0 * N) + (uint32_t)(t.hg * AW * d), N);
+    if (HAS_MASK && lane < 32) sMask[lane] = (lane < L && t.hg * AW + wid < heads) ? a.mask[r0 + lane] : 0.f;
+  };
   __syncthreads();                                       // images zeroed, bias table in LDS
-  if (nx.sb < nseq) prefetch(nx);
+  if (nseq <= (int)blockIdx.x) return;                   // uniform: nothing for this workgroup
+  prefetch(nx);
+  put(nx);
+  __syncthreads();
+  // rotated software pipeline, see fwd_kernel: loads(i+1) | compute(i) | stores(i) | item i+1 -> LDS with a counted wait
   for (; it.sb < nseq; it.next(hgroups, stride)) {
     const int head = it.hg * AW + wid;
-    const bool active = head < a.heads;
-    const size_t row0 = (size_t)sq_next * L;             // taken before the next prefetch overwrites it
+    const bool active = head < heads;
+    const size_t row0 = (size_t)sq_next * L;             // the current item's sequence: taken before the prefetch overwrites it
     const int Ls = active ? L : 0;
-    if (SUB && dead_next) {
-      const int hoff = it.hg * AW * d, hcount = min(AW, a.heads - it.hg * AW);
-      panel_put_bias(imQ, pc, sBias + hoff, hcount);
-      panel_put_bias(imK, pc, sBias + N + hoff, hcount);
-      panel_put_bias(imV, pc, sBias + 2 * N + hoff, hcount);
-    } else {
-      panel_put<false>(rq, imQ, pc, nodrop, 0, 0);
-      panel_put<false>(rk, imK, pc, nodrop, 0, 0);
-      panel_put<false>(rv, imV, pc, nodrop, 0, 0);
-    }
-    panel_put<true>(rg, imG, pc, a.drop, (uint32_t)(row0 * N) + (uint32_t)(it.hg * AW * d), N);
-    if (HAS_MASK && lane < 32) sMask[lane] = (lane < Ls) ? a.mask[row0 + lane] : 0.f;
-    __syncthreads();
     nx.next(hgroups, stride);
-    if (nx.sb < nseq) prefetch(nx);
+    const ItemIter pf = nx.sb < nseq ? nx : it;
+    prefetch(pf);
     f32x16 dst;  // dS^T (lane = query i), carries the 1/sqrt(d) factor of dQ and dK
     {
       f32x16 st, dpt;
@@ -924,7 +1017,7 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
     }
     // stored straight from the registers: routing dQ/dK/dV through LDS panels like the forward output measured
     // slower here (1.38 vs 1.18 ms)
-    if (3 * 32 * AW * d <= 2 * AW * IMG) {                // d <= 21
+    if (FULL || 3 * 32 * AW * d <= 2 * AW * IMG) {        // d <= 21 (FULL is only launched for such shapes)
       // dQ|dK|dV leave through three [32][AW*d] panels that ALIAS the (now dead) Q and V images: the workgroup then
       // stores consecutive 8-byte pieces, 160-byte runs per row and matrix instead of 40-byte head slivers
       const int ops = AW * d;
@@ -934,16 +1027,24 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
       acc_t_to_panel<false>(dv, img0 + 64 * ops, ops, wid, Ls, d, lane, nodrop, 0, 0);
       __syncthreads();
       bf16_t* op = dqkv + row0 * N3 + it.hg * AW * d;
-      const int hcount = min(AW, a.heads - it.hg * AW);
-      panel_store<PT>(img0, ops, op, N3, pc, hcount);
-      panel_store<PT>(img0 + 32 * ops, ops, op + N, N3, pc, hcount);
-      panel_store<PT>(img0 + 64 * ops, ops, op + 2 * N, N3, pc, hcount);
+      const int hcount = min(AW, heads - it.hg * AW);
+      if (FULL) {
+        panel_store_all<PT>(img0, ops, op, N3, pc);
+        panel_store_all<PT>(img0 + 32 * ops, ops, op + N, N3, pc);
+        panel_store_all<PT>(img0 + 64 * ops, ops, op + 2 * N, N3, pc);
+      } else {
+        panel_store<PT>(img0, ops, op, N3, pc, hcount);
+        panel_store<PT>(img0 + 32 * ops, ops, op + N, N3, pc, hcount);
+        panel_store<PT>(img0 + 64 * ops, ops, op + 2 * N, N3, pc, hcount);
+      }
     } else {                                              // wider heads: the panels would not fit into two image groups
       bf16_t* op = dqkv + row0 * N3 + (active ? head : 0) * d;
       acc_t_to_global<false>(dq, op, N3, Ls, d, lane, nodrop, 0, 0);
       acc_t_to_global<false>(dk, op + N, N3, Ls, d, lane, nodrop, 0, 0);
       acc_t_to_global<false>(dv, op + 2 * N, N3, Ls, d, lane, nodrop, 0, 0);
     }
+    __syncthreads();   // every wave has read the output panels (they alias the Q / V images)
+    put(pf);           // next item -> images
     __syncthreads();
   }
 }
@@ -1363,11 +1464,25 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   const bool p3 = a.L * a.d <= 768, sub = a.tmask != nullptr;
   const size_t smem_s = smem + (sub ? (size_t)3 * a.N * sizeof(bf16_t) : 0);
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(AW * 64), smem_s, stream, a); };
+  // FULL: all head slots real and the store panels alias the images (d <= 21 in the backward): unpredicated memory
+  // instructions, counted waits (see fwd_kernel)
+  const bool full = a.heads % AW == 0 && a.L * a.d >= 64 && (!bwd || 3 * 32 * AW * a.d <= 2 * AW * IMG) && !nr_opt(NR_OPT_ATTN_PRED);
+  const bool title30 = full && p3 && a.L == 30 && a.d == 20 && a.heads == 20 && !nr_opt(NR_OPT_ATTN_GENERIC);   // the reference's defaults
   auto pick = [&](auto tag_mask, auto tag_sub) {
     constexpr bool HM = decltype(tag_mask)::value, SB = decltype(tag_sub)::value;
-    if (bwd) p3 ? go(bwd_kernel<HM, 3, SB>) : go(bwd_kernel<HM, 4, SB>);
-    else if (!SB && a.ids != nullptr) p3 ? go(fwd_kernel<HM, 3, false, true>) : go(fwd_kernel<HM, 4, false, true>);
-    else p3 ? go(fwd_kernel<HM, 3, SB>) : go(fwd_kernel<HM, 4, SB>);
+    if (bwd) {
+      if (title30) go(bwd_kernel<HM, 3, SB, true, 30, 20, 20>);
+      else if (full) p3 ? go(bwd_kernel<HM, 3, SB, true>) : go(bwd_kernel<HM, 4, SB, true>);
+      else p3 ? go(bwd_kernel<HM, 3, SB>) : go(bwd_kernel<HM, 4, SB>);
+    } else if (!SB && a.ids != nullptr) {
+      p3 ? go(fwd_kernel<HM, 3, false, true>) : go(fwd_kernel<HM, 4, false, true>);
+    } else if (title30) {
+      go(fwd_kernel<HM, 3, SB, false, true, 30, 20, 20>);
+    } else if (full) {
+      p3 ? go(fwd_kernel<HM, 3, SB, false, true>) : go(fwd_kernel<HM, 4, SB, false, true>);
+    } else {
+      p3 ? go(fwd_kernel<HM, 3, SB>) : go(fwd_kernel<HM, 4, SB>);
+    }
   };
   if (a.mask) sub ? pick(std::true_type{}, std::true_type{}) : pick(std::true_type{}, std::false_type{});
   else sub ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
@@ -1412,10 +1527,10 @@ bool nr_attn_pad_ok(int dtype, int L, int d_head, const void* p0, const void* p1
 
 int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask, void* y, const void* dy, void* dqkv, int n,
                         int L, int heads, int d_head, const DropCfg& drop, hipStream_t stream, const uint32_t* tmask,
-                        const float* bias, const int32_t* seq_list, const int32_t* seq_count) {
+                        const float* bias, const int32_t* seq_list, const int32_t* seq_count, const int32_t* needed) {
   if (!nr_attn_mfma_supported(L, d_head)) return -1;
   AttnMArgs a;
-  a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr; a.ids = nullptr;
+  a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr; a.ids = nullptr; a.needed = needed;
   a.qkv = qkv; a.mask = mask; a.y = y; a.dy = dy; a.dqkv = dqkv;
   a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;
   a.scale = 1.0f / sqrtf((float)d_head);
@@ -1447,7 +1562,7 @@ int nr_launch_attn_gather_fwd(const void* proj_table, const int32_t* ids, const 
                               int d_head, const DropCfg& drop, hipStream_t stream) {
   if (!nr_attn_pad_ok(NR_BF16, L, d_head, proj_table, y) || ids == nullptr) return -1;
   AttnMArgs a;
-  a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr;
+  a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr; a.needed = nullptr;
   a.ids = ids;
   a.qkv = proj_table; a.mask = mask; a.y = y; a.dy = nullptr; a.dqkv = nullptr;
   a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;

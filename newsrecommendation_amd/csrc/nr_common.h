@@ -88,6 +88,8 @@ enum NrOpt {
   NR_OPT_NT_NODMA,       // 1: no LDS-DMA NT kernel
   NR_OPT_DMA_MIN_K,      // smallest K that takes the LDS-DMA NT kernel (default 192)
   NR_OPT_DMA_WM2_ALL,    // 1: 128-row DMA tiles for every N
+  NR_OPT_ATTN_PRED,      // 1: predicated (pre-"FULL") memory instructions in the bf16 panel attention kernels
+  NR_OPT_ATTN_GENERIC,   // 1: no shape-specialised (L=30, 20 heads of 20) instantiation of the panel attention kernels
   NR_OPT_COUNT
 };
 int nr_opt(int which);

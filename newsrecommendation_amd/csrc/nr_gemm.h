@@ -43,7 +43,9 @@ struct EpiArgs {
   const int32_t* row_count;  // SCATTER / STORE (bf16 DMA kernel), optional compaction (nr_launch_compact_rows): device count of live rows,
   const int32_t* row_idx;    //   their original row numbers (A row, dropout element index) and
   const int32_t* row_ids;    //   their token ids, both in compacted order
-  const int32_t* seq_nz;     // POOLBWD, optional [M / L]: 0 = this sequence's rowscale-term operand g and its A rows are all zero
+  const int32_t* seq_nz;     // POOLBWD, optional [M / L]: 0 = this sequence's rowscale-term operand g and its A rows are all zero;
+                             // STORE / STORE_TANH (dense rows), optional [M / L]: 0 = nobody needs this sequence's output rows: row
+                             // tiles made of such sequences only are skipped (their rows stay unwritten)
   void* rows_out;         // optional: the staged A rows (after gather / dropout), dtype, [M, ld_rows_out]
   int ld_rows_out;
 };

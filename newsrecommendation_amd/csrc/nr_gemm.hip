@@ -988,6 +988,13 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
       }
     }
   }
+  if ((EPI == EPI_STORE || EPI == EPI_STORE_TANH) && ep.seq_nz != nullptr && ep.row_count == nullptr) {
+    // every sequence of this row tile is flagged "output not needed": nothing is computed, the rows stay unwritten
+    const int t_first = m0 / ep.L, t_last = (min(m0 + DBM, M) - 1) / ep.L;
+    bool live = false;
+    for (int t = t_first + tid; t <= t_last; t += WTHR) live |= ep.seq_nz[t] != 0;
+    if (!__syncthreads_or(live)) return;
+  }
   const bool compact = (EPI == EPI_SCATTER || EPI == EPI_STORE) && ep.row_count != nullptr;
   if (compact) {
     M = *ep.row_count;                             // rows that survive the compaction (device side, no host sync)

@@ -54,12 +54,18 @@ template <typename T>
 __global__ __launch_bounds__(256) void pool_fwd_kernel(const T* __restrict__ x, const T* __restrict__ e,
                                                        const float* __restrict__ w2, const float* __restrict__ b2,
                                                        const float* __restrict__ mask, float* __restrict__ alpha,
-                                                       float* __restrict__ out, int ld_out, int L, int N, int q) {
+                                                       float* __restrict__ out, int ld_out, int L, int N, int q,
+                                                       const int32_t* __restrict__ needed) {
   constexpr int CH = ChunkOf<T>::CH;
   __shared__ float sS[64];
   __shared__ float sRed[POOL_RED_FLOATS];
   const int seq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t row0 = (size_t)seq * L;
+  if (needed != nullptr && needed[seq] == 0) {             // nobody uses this sequence's vector: zeros, x / e are not read
+    for (int l = tid; l < L; l += 256) alpha[row0 + l] = 0.f;
+    for (int c = tid; c < N; c += 256) out[(size_t)seq * ld_out + c] = 0.f;
+    return;
+  }
   for (int l = wid; l < L; l += 4) {
     const float p = wave_row_dot<T>(e + (row0 + l) * q, w2, q / CH, lane);
     if (lane == 0) sS[l] = p + b2[0];
@@ -461,14 +467,14 @@ inline int grid_for(size_t total, int block = 256, int cap = 256 * 16) {
 
 // ---- launchers used by nr_api.hip ---------------------------------------------------------
 int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
-                            float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s) {
+                            float* alpha, float* out, int ld_out, int n, int L, int N, int q, hipStream_t s, const int32_t* needed) {
   NR_CHECK_ARG(L >= 1 && L <= 64, "additive_pool: L=%d must be in [1, 64]", L);
   NR_CHECK_ARG((((uintptr_t)x | (uintptr_t)e) & 15) == 0 && q <= 1024, "additive_pool: x / e must be 16-byte aligned, q <= 1024");
   NrProfScope ps(s, "pool_core_fwd[n=%d,L=%d,N=%d,q=%d]", n, L, N, q);
   if (dtype == NR_BF16)
-    hipLaunchKernelGGL(pool_fwd_kernel<bf16_t>, dim3(n), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)e, w2, b2, mask, alpha, out, ld_out, L, N, q);
+    hipLaunchKernelGGL(pool_fwd_kernel<bf16_t>, dim3(n), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)e, w2, b2, mask, alpha, out, ld_out, L, N, q, needed);
   else
-    hipLaunchKernelGGL(pool_fwd_kernel<float>, dim3(n), dim3(256), 0, s, (const float*)x, (const float*)e, w2, b2, mask, alpha, out, ld_out, L, N, q);
+    hipLaunchKernelGGL(pool_fwd_kernel<float>, dim3(n), dim3(256), 0, s, (const float*)x, (const float*)e, w2, b2, mask, alpha, out, ld_out, L, N, q, needed);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }

@@ -23,11 +23,14 @@ class NewsEncoder(nn.Module):
                                                            self.dim_per_head, self.dim_per_head, compute_dtype=_cd(args))
         self.attn = AttentionPooling(args.news_dim, args.news_query_vector_dim, compute_dtype=_cd(args))
 
-    def forward(self, x, mask=None):
-        """x: [n, word_num] token ids; mask: [n, word_num] or None -> [n, news_dim] fp32."""
+    def forward(self, x, mask=None, needed=None):
+        """x: [n, word_num] token ids; mask: [n, word_num] or None -> [n, news_dim] fp32.
+        needed (beyond the reference): optional [n] flags; 0 = the caller multiplies this title's vector by zero (a masked
+        history slot): it is returned as zeros without being encoded."""
         p = self.drop_rate if self.training else 0.0
-        y = self.multi_head_self_attn.forward_gather(x, self.embedding_matrix.weight, mask=mask, p_in=p, p_out=p)
-        return self.attn(y, mask)
+        needed = ops.needed_flags(needed)
+        y = self.multi_head_self_attn.forward_gather(x, self.embedding_matrix.weight, mask=mask, p_in=p, p_out=p, needed=needed)
+        return self.attn(y, mask, needed=needed)
 
 
 class UserEncoder(nn.Module):
@@ -87,7 +90,13 @@ class Model(torch.nn.Module):
             live = (history_mask.reshape(-1) != 0).nonzero(as_tuple=False).squeeze(1)     # host sync: the count
             vecs = self.news_encoder(torch.cat([cand, hist.index_select(0, live)], dim=0))
         else:
-            vecs = self.news_encoder(torch.cat([cand, hist], dim=0))
+            # History slots with mask 0 reach the loss through a factor 0 only (pad-doc blend NRMS.py:59-60, or masked out of
+            # the user-level attention and pooling, model_utils.py:28,51): the encoder is told, and returns zeros for them
+            # without computing them.  Same loss, scores and gradients; `args.encode_masked_slots=True` switches it off.
+            needed = None
+            if not getattr(a, "encode_masked_slots", False):
+                needed = torch.cat([history_mask.new_ones(B * C), history_mask.reshape(-1)])
+            vecs = self.news_encoder(torch.cat([cand, hist], dim=0), needed=needed)
         # split, not two slices: its backward is one concatenation instead of two zero-filled full-size buffers and an add
         cand_flat, hist_flat = vecs.split([B * C, vecs.shape[0] - B * C], dim=0)
         if compact:

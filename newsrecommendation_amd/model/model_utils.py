@@ -20,13 +20,14 @@ class AttentionPooling(nn.Module):
         self.att_fc2 = nn.Linear(hidden_size, 1)
         self.compute_dtype = compute_dtype
 
-    def forward(self, x, attn_mask=None):
-        """x: [batch, L, emb]; attn_mask: [batch, L] -> [batch, emb] (fp32)."""
+    def forward(self, x, attn_mask=None, needed=None):
+        """x: [batch, L, emb]; attn_mask: [batch, L] -> [batch, emb] (fp32).
+        needed (beyond the reference): optional [batch] int32 flags, 0 = the caller multiplies this row's vector by zero."""
         code = ops.dtype_code(self.compute_dtype)
         if x.dtype != ops.torch_dtype(code):
             x = ops.to_compute(x.float(), code)
         return ops.additive_pool(x, self.att_fc1.weight, self.att_fc1.bias, self.att_fc2.weight, self.att_fc2.bias,
-                                 code, mask=attn_mask)
+                                 code, mask=attn_mask, needed=needed)
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -80,8 +81,8 @@ class MultiHeadSelfAttention(nn.Module):
         return ops.mhsa(x, *self._params(), heads=self.n_heads, code=code, mask=mask, p_out=p_out,
                         flat=getattr(self, "_nr_flat", None))
 
-    def forward_gather(self, ids, table, mask=None, p_in=0.0, p_out=0.0):
+    def forward_gather(self, ids, table, mask=None, p_in=0.0, p_out=0.0, needed=None):
         """Embedding lookup + dropout + MHSA + dropout in one op: ids int32 [batch, L] into `table` [V, d_model]."""
         code = ops.dtype_code(self.compute_dtype)
         return ops.mhsa(None, *self._params(), heads=self.n_heads, code=code, mask=mask, ids=ids, table=table,
-                        p_in=p_in, p_out=p_out, flat=getattr(self, "_nr_flat", None))
+                        p_in=p_in, p_out=p_out, flat=getattr(self, "_nr_flat", None), needed=needed)

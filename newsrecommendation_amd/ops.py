@@ -283,7 +283,7 @@ class MHSAFunction(Function):
                           src_kind=NR_SRC_GATHER if gather else NR_SRC_DENSE, x=ptr(src), ldx=ldx, ids=ptr(ids),
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
-                          x_rows=ptr(x_rows), ld_rows=Kp)
+                          x_rows=ptr(x_rows), ld_rows=Kp, seq_needed=ptr(cfg.get("needed")))
         # scratch for the device-side compaction of non-padding rows (forward: live rows, their ids, padding rows;
         # backward: live slabs, sequence list) -- sized by the library
         row_ws = _ws(_lib.lib().nr_mhsa_workspace_bytes(C.byref(d)), dev) if keep_rows and code == _lib.NR_BF16 else None
@@ -367,11 +367,21 @@ def _mhsa_projected(table, params, flat, ids, mask, heads, code, p_out):
     return y
 
 
-def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int, code: int, mask=None, ids=None, table=None, p_in=0.0, p_out=0.0, flat=None):
+def needed_flags(needed):
+    """[n] int32 flags (1 = the caller uses this sequence's output) from a bool / float / int tensor, or None."""
+    if needed is None:
+        return None
+    return (needed.reshape(-1) != 0).to(torch.int32).contiguous()
+
+
+def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int, code: int, mask=None, ids=None, table=None, p_in=0.0, p_out=0.0, flat=None,
+         needed=None):
     """Dense: x [n, L, d_model] (compute dtype).  Gather: ids int32 [n, L] + fp32 `table` parameter.
-    flat: {"w": [3N, d_model], "b": [3N], "gw", "gb"} views of a flat parameter / gradient bucket (parallel.FlatBucket)."""
+    flat: {"w": [3N, d_model], "b": [3N], "gw", "gb"} views of a flat parameter / gradient bucket (parallel.FlatBucket).
+    needed: optional [n] int32 flags (needed_flags): sequences with flag 0 reach the loss through a factor 0 only; their
+    output rows are exact zeros and are not computed (their gradient is zero, so nothing flows back either)."""
     cfg = dict(code=code, heads=heads, p_in=float(p_in), p_out=float(p_out),
-               seed_in=draw_seed() if p_in > 0 else 0, seed_out=draw_seed() if p_out > 0 else 0)
+               seed_in=draw_seed() if p_in > 0 else 0, seed_out=draw_seed() if p_out > 0 else 0, needed=needed)
     if flat is not None:
         cfg["flat"] = flat
     if ids is not None:
@@ -453,7 +463,7 @@ class PoolFunction(Function):
     """K5: AttentionPooling.forward, src/model/model_utils.py:13-31."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, mask, code):
+    def forward(ctx, x, w1, b1, w2, b2, mask, code, needed=None):
         _need_gpu(x, w1, mask)
         n, L, N = x.shape
         q = w1.shape[0]
@@ -468,9 +478,10 @@ class PoolFunction(Function):
         alpha = torch.empty(n * L, dtype=torch.float32, device=dev)
         out = torch.empty(n, N, dtype=torch.float32, device=dev)
         d = _lib.PoolDesc(n=n, L=L, N=N, q=q, dtype=code, x=ptr(x), mask=ptr(mask_c), w1=ptr(w1_p), ldw1=w1_p.shape[1],
-                          b1=ptr(b1_c), w2=ptr(w2_c), b2=ptr(b2_c))
+                          b1=ptr(b1_c), w2=ptr(w2_c), b2=ptr(b2_c), seq_needed=ptr(needed))
         check(_lib.lib().nr_additive_pool_fwd(C.byref(d), ptr(e), ptr(alpha), ptr(out), N, _stream()), "nr_additive_pool_fwd")
         ctx.code, ctx.dims = code, (n, L, N, q)
+        ctx.needed = needed
         ctx.targets = tuple(grad_target(p) for p in (w1, b1, w2, b2)) if torch.is_grad_enabled() else (None,) * 4
         ctx.save_for_backward(x, mask_c, w1_p, b1_c, w2_c, b2_c, e, alpha, w1)
         return out
@@ -493,7 +504,7 @@ class PoolFunction(Function):
             dw1, db1, dw2, db2 = flat[:q * N].view(q, N), flat[q * N:q * N + q], flat[q * N + q:q * N + 2 * q], flat[q * N + 2 * q:q * N + 2 * q + 1]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         d = _lib.PoolDesc(n=n, L=L, N=N, q=q, dtype=code, x=ptr(x), mask=ptr(mask_c), w1=ptr(w1_p), ldw1=w1_p.shape[1],
-                          b1=ptr(b1_c), w2=ptr(w2_c), b2=ptr(b2_c))
+                          b1=ptr(b1_c), w2=ptr(w2_c), b2=ptr(b2_c), seq_needed=ptr(ctx.needed))
         partial = _ws(_lib.lib().nr_pool_workspace_bytes(C.byref(d)), dev)      # per-workgroup partial rows + slab scratch
         d.partial_bytes = partial.numel() * 4
         check(_lib.lib().nr_additive_pool_bwd(C.byref(d), ptr(e), ptr(alpha), ptr(g), N, ptr(w1_t),
@@ -501,12 +512,13 @@ class PoolFunction(Function):
                                               ptr(db1), ptr(dw2), ptr(db2), ptr(dx), _stream()), "nr_additive_pool_bwd")
         _offer_flags(seq, dx, n, _lib.lib().nr_pool_seq_flags(C.byref(d), ptr(partial)), partial)
         if direct:
-            return dx, None, None, None, None, None, None
-        return dx, dw1, db1, dw2.view(1, q), db2, None, None
+            return dx, None, None, None, None, None, None, None
+        return dx, dw1, db1, dw2.view(1, q), db2, None, None, None
 
 
-def additive_pool(x, w1, b1, w2, b2, code: int, mask=None):
-    return PoolFunction.apply(x, w1, b1, w2, b2, mask, code)
+def additive_pool(x, w1, b1, w2, b2, code: int, mask=None, needed=None):
+    """needed: optional [n] int32 flags (needed_flags): flag 0 = the pooled vector is not used: zeros, nothing computed."""
+    return PoolFunction.apply(x, w1, b1, w2, b2, mask, code, needed)
 
 
 # ------------------------------------------------------------------------------------------ pad blend / cast
