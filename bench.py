@@ -114,7 +114,7 @@ def batch_structure(batches, args, model_name):
     share of token rows with a non-padding id (`*_live` NT GEMMs), share of 32-row slabs that touch a title with a
     non-zero upstream gradient (`gemm_tn3_live`), share of sequences the attention backward walks."""
     T = args.num_words_title
-    live_rows, live_slabs, live_seq, live_titles = [], [], [], []
+    live_rows, live_slabs, live_seq, live_titles, needed = [], [], [], [], []
     for hist, mask, cand, _ in batches:
         B, H = mask.shape
         C = cand.shape[1]
@@ -127,6 +127,7 @@ def batch_structure(batches, args, model_name):
             live_rows.append(1.0)
             allpad = torch.zeros_like(nz_title, dtype=torch.bool)
         live_titles.append(float((~allpad).float().mean()))
+        needed.append(float(nz_title.mean()))
         M = nz_title.numel() * T
         row_nz = nz_title.repeat_interleave(T)
         pad = (-M) % 32
@@ -135,7 +136,7 @@ def batch_structure(batches, args, model_name):
         near = torch.nn.functional.max_pool1d(nz_title[None, None], kernel_size=7, stride=1, padding=3)[0, 0] > 0
         live_seq.append(float((~(allpad & ~near)).float().mean()))
     avg = lambda x: sum(x) / len(x)
-    return {"live_token_rows": round(avg(live_rows), 4), "live_titles": round(avg(live_titles), 4),
+    return {"live_token_rows": round(avg(live_rows), 4), "live_titles": round(avg(live_titles), 4), "needed_titles": round(avg(needed), 4),
             "live_gradient_slabs": round(avg(live_slabs), 4), "attention_bwd_sequences": round(avg(live_seq), 4)}
 
 
@@ -171,8 +172,10 @@ def price_kernel(label, avg_ms, struct, dtype):
         elif "gather" in name:
             by = rows * (3 * N + N) * esz                        # gather projected Q|K|V rows (L2 / MALL), write y
         elif "fwd" in name:
-            # read Q|K|V of the titles that have any live token (all-padding titles substitute the bias), write y of all
-            by = rows * (3 * N * struct.get("live_titles", 1.0) + N) * esz
+            # read Q|K|V of the titles that have any live token (all-padding titles substitute the bias); write y of all
+            # titles, or ("_live": the kernel walks the needed titles, a store-only kernel zero-fills the rest) of the needed ones
+            wfrac = struct.get("needed_titles", 1.0) if name.endswith("_live") else 1.0
+            by = rows * (3 * N * min(struct.get("live_titles", 1.0), wfrac) + N * wfrac) * esz
         else:
             by = rows * (3 * N + N + 3 * N) * esz                # read Q|K|V + dy, write dQ|dK|dV
             if name.endswith("_live"):
@@ -415,7 +418,8 @@ def run_eval(a, args, device, rank, world, dist_on):
     if rank != 0:
         return
     sums = sums.cpu().tolist()
-    struct = {"live_token_rows": float((comb != 0).mean()), "live_titles": 1.0, "live_gradient_slabs": 1.0, "attention_bwd_sequences": 1.0}
+    struct = {"live_token_rows": float((comb != 0).mean()), "live_titles": 1.0, "needed_titles": 1.0, "live_gradient_slabs": 1.0,
+              "attention_bwd_sequences": 1.0}
     out = {"metric": "eval impressions/sec (full-corpus encode + scoring + ranking metrics), NRMS", "value": round(n * world * a.steps / dt, 1),
            "unit": "impressions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",

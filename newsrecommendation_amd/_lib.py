@@ -35,7 +35,8 @@ class ConvDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("T", C.c_int), ("D", C.c_int), ("Dp", C.c_int), ("N", C.c_int), ("dtype", C.c_int),
                 ("table", C.c_void_p), ("ids", C.c_void_p), ("ids_stride", C.c_int), ("p_in", C.c_float),
                 ("seed_in", C.c_uint32), ("w_pack", C.c_void_p), ("bias", C.c_void_p), ("x_rows", C.c_void_p),
-                ("ld_rows", C.c_int), ("bwd_ws", C.c_void_p), ("bwd_ws_bytes", C.c_size_t), ("seq_nz", C.c_void_p)]
+                ("ld_rows", C.c_int), ("bwd_ws", C.c_void_p), ("bwd_ws_bytes", C.c_size_t), ("seq_nz", C.c_void_p),
+                ("seq_needed", C.c_void_p)]
 
 
 class PoolDesc(C.Structure):

@@ -483,8 +483,17 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
     }
   }
   if ((rc = nr_launch_gemm_nt(d->dtype, A, d->w_qkv, d->ldw, M, 3 * N, Kp, EPI_STORE, ep, s))) return rc;
+  // "output not needed" flags: with the compaction scratch at hand the attention kernel walks a device-side list of the
+  // needed sequences and a store-only kernel zero-fills the y rows of the others; without it the kernel skips in place
+  const int32_t* fwd_list = nullptr;
+  if (d->seq_needed != nullptr && tmask != nullptr && ((size_t)d->L * N * nr_elt_size(d->dtype)) % 16 == 0 && (((uintptr_t)y) & 15) == 0) {
+    int32_t* lw = d->row_ws + W.seq;
+    if ((rc = nr_launch_needed_list(d->seq_needed, d->n, lw, y, (size_t)d->L * N * nr_elt_size(d->dtype), s))) return rc;
+    fwd_list = lw;
+  }
   return nr_launch_attn(false, d->dtype, qkv, d->mask, y, nullptr, nullptr, d->n, d->L, d->heads, d->d_head,
-                        nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr, nullptr, nullptr, d->seq_needed);
+                        nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr, fwd_list ? fwd_list + 4 : nullptr, fwd_list,
+                        fwd_list ? nullptr : d->seq_needed);
 }
 
 int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dqkv, const void* w_qkv_t, int ldwt,
@@ -609,6 +618,7 @@ int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream) {
   NR_CHECK_ARG(y != nullptr, "conv1d_fwd: null output");
   NR_DEVICE_GUARD(stream, y);
   EpiArgs ep = store_epi(y, d->N, d->dtype, d->bias, 0);
+  ep.seq_nz = d->seq_needed; ep.L = d->T;          // row tiles made of unneeded titles only are not computed
   hipStream_t s = (hipStream_t)stream;
   const int M = d->n * d->T, K = 3 * d->Dp;
   if (d->x_rows != nullptr) {

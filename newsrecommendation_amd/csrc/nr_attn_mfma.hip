@@ -749,7 +749,10 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   // rows and ignore them), the per-sequence flag comes through the scalar cache -- nothing in the loop waits on vmcnt(0),
   // so the stores of item i drain while item i+1 is computed.
   const int hgroups = (heads + AW - 1) / AW, stride = gridDim.x;
-  ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};   // blockIdx.x < n by launch
+  ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};
+  const bool listed = a.seq_list != nullptr;             // walk a device-side list of sequences (the others were zero-filled)
+  const int nseq = listed ? *a.seq_count : a.n;
+  int sq_next = 0;                                       // the sequence sitting in the prefetch registers
   Panel<PT> rq, rk, rv;
   bool dead_next = false;                                // the item sitting in rq / rk / rv is all padding
   bool dead_seq = false;                                 // ... of the sequence the prefetcher is in
@@ -758,24 +761,27 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   auto prefetch = [&](const ItemIter& t) {
     const int hoff = t.hg * AW * d;
     const int hcount = min(AW, heads - t.hg * AW);
-    if (SUB && (t.hg == 0 || !FULL))                     // a sequence of padding tokens only: Q|K|V = bias, nothing to load
-      dead_seq = (FULL ? sload_u32(a.tmask + __builtin_amdgcn_readfirstlane(t.sb)) : a.tmask[t.sb]) == 0;
-    if (has_needed && (t.hg == 0 || !FULL))
-      skip_seq = (FULL ? sload_u32(a.needed + __builtin_amdgcn_readfirstlane(t.sb)) : (uint32_t)a.needed[t.sb]) == 0;
+    if (t.hg == 0 || !FULL) {
+      const int sbu = __builtin_amdgcn_readfirstlane(t.sb);
+      sq_next = !listed ? sbu : (FULL ? (int)sload_u32(a.seq_list + sbu) : a.seq_list[sbu]);
+      if (SUB)                                           // a sequence of padding tokens only: Q|K|V = bias, nothing to load
+        dead_seq = (FULL ? sload_u32(a.tmask + sq_next) : a.tmask[sq_next]) == 0;
+      if (has_needed) skip_seq = (FULL ? sload_u32(a.needed + sq_next) : (uint32_t)a.needed[sq_next]) == 0;
+    }
     skip_next = has_needed && skip_seq;
     dead_next = (SUB && dead_seq) || (FULL && skip_next);   // FULL: a skipped sequence loads like a dead one (rows ignored)
     if (GATHER) {
-      const int32_t* idp = a.ids + (size_t)t.sb * L;
+      const int32_t* idp = a.ids + (size_t)sq_next * L;
       panel_load_g(rq, qkv, N3, idp, hoff, pc, hcount);
       panel_load_g(rk, qkv, N3, idp, N + hoff, pc, hcount);
       panel_load_g(rv, qkv, N3, idp, 2 * N + hoff, pc, hcount);
     } else if (FULL) {
-      const bf16_t* src = qkv + (dead_next ? (size_t)0 : (size_t)t.sb * L * N3) + hoff;   // dead: any valid rows (L2 hits), ignored
+      const bf16_t* src = qkv + (dead_next ? (size_t)0 : (size_t)sq_next * L * N3) + hoff;   // dead: any valid rows (L2 hits), ignored
       panel_load_all(rq, src, N3, pc);
       panel_load_all(rk, src + N, N3, pc);
       panel_load_all(rv, src + 2 * N, N3, pc);
     } else if (!dead_next) {
-      const bf16_t* src = qkv + (size_t)t.sb * L * N3 + hoff;
+      const bf16_t* src = qkv + (size_t)sq_next * L * N3 + hoff;
       panel_load(rq, src, N3, pc, hcount);
       panel_load(rk, src + N, N3, pc, hcount);
       panel_load(rv, src + 2 * N, N3, pc, hcount);
@@ -795,10 +801,11 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
       panel_put<false, PT, FULL>(rk, img0 + IMG, pc, nodrop, 0, 0);
       panel_put<false, PT, FULL>(rv, img0 + 2 * IMG, pc, nodrop, 0, 0);
     }
-    if (HAS_MASK && lane < 32) sMask[lane] = (lane < L && t.hg * AW + wid < heads) ? a.mask[(size_t)t.sb * L + lane] : 0.f;
+    if (HAS_MASK && lane < 32) sMask[lane] = (lane < L && t.hg * AW + wid < heads) ? a.mask[(size_t)sq_next * L + lane] : 0.f;
     skip_cur = skip_next;
   };
   __syncthreads();                                       // images zeroed, bias table in LDS
+  if (nseq <= (int)blockIdx.x) return;                   // uniform: nothing for this workgroup
   prefetch(nx);
   put(nx);
   __syncthreads();
@@ -806,13 +813,13 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   // are older than the stores in the in-order vmcnt queue and both sit in one straight-line stretch of the loop body, so
   // the wait before the LDS writes is a COUNTED one (vmcnt = number of stores): the stores of item i drain while item i+1
   // is computed instead of stalling the wave at the top of the next iteration.
-  for (; it.sb < a.n; it.next(hgroups, stride)) {
+  for (; it.sb < nseq; it.next(hgroups, stride)) {
     const int head = it.hg * AW + wid;
     const bool active = head < heads;
-    const size_t row0 = (size_t)it.sb * L;
+    const size_t row0 = (size_t)sq_next * L;             // the current item's sequence: taken before the prefetch overwrites it
     const int Ls = active ? L : 0;                       // inactive waves store nothing
     nx.next(hgroups, stride);
-    const ItemIter pf = nx.sb < a.n ? nx : it;           // the last item loads itself again: same instruction stream everywhere
+    const ItemIter pf = nx.sb < nseq ? nx : it;          // the last item loads itself again: same instruction stream everywhere
     prefetch(pf);
     f32x16 ctx;
 #pragma unroll
@@ -855,7 +862,9 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
 }
 
 template <bool HAS_MASK, int PT, bool SUB, bool FULL = false, int LC = 0, int DC = 0, int HC = 0>
-__global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void bwd_kernel(AttnMArgs a) {
+// the shape-specialised instantiation fits 128 VGPRs (4 waves per SIMD: 0.75 -> 0.71 ms); the generic ones need ~160 and
+// would spill under that cap (1.6 - 2.3 ms)
+__global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(LC ? 4 : 3, LC ? 4 : 3))) void bwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR address math
   // Image block, MATRIX-major: [Q x AW waves | V x AW | K x AW | G x AW].  The output panels of an item are written over
@@ -1541,7 +1550,7 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   const bool fast = dtype == NR_BF16 && a.vec && !old_path;
   if (L > 32 && !fast) return -1;   // caller falls back to the LDS/VALU kernels
   // "_live": the backward walks a device-side list of sequences (n is then an upper bound)
-  NrProfScope ps(stream, "attn_mfma_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? (seq_list ? "bwd_live" : "bwd") : "fwd",
+  NrProfScope ps(stream, "attn_mfma_%s[%s,n=%d,L=%d,h=%d,d=%d]", bwd ? (seq_list ? "bwd_live" : "bwd") : (seq_list ? "fwd_live" : "fwd"),
                  dtype == NR_BF16 ? "bf16" : "f32", n, L, heads, d_head);
   if (tmask != nullptr) {
     if (!(fast && L <= 32 && bias != nullptr)) {
@@ -1551,6 +1560,7 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
     a.tmask = tmask; a.bias = bias;
     if (bwd && seq_list != nullptr) { a.seq_list = seq_list; a.seq_count = seq_count; }
   }
+  if (!bwd && fast && L <= 32 && seq_list != nullptr) { a.seq_list = seq_list; a.seq_count = seq_count; }   // forward: needed sequences only
   if (fast) return b16::launch(bwd, a, stream);
   return dtype == NR_BF16 ? launch_t<bf16_t>(bwd, a, stream) : launch_t<float>(bwd, a, stream);
 }

@@ -1334,7 +1334,9 @@ int launch_nt_dma_p(const RowSrc& A, const void* B, int ldb, int M, int N, int K
   // (QKV projection: 1.45 -> 1.57 ms)
   constexpr bool fits2 = 3 * (8 + NT16) * 1024 <= 78 * 1024;
   const bool wm2_all = nr_opt(NR_OPT_DMA_WM2_ALL) != 0;
-  if (fits2 && (N <= NT16 * 16 || wm2_all)) return launch_nt_dma_w<EPI, NT16, PK, 2>(A, B, ldb, M, N, K, ep, stream);
+  // short contractions (K <= 224: at most 7 k-steps) are all pipeline fill and epilogue: two workgroups per CU overlap
+  // them even with two column chunks (pooling dX, N = 400, K = 200: 0.445 -> 0.372 ms)
+  if (fits2 && (N <= NT16 * 16 || K <= 224 || wm2_all)) return launch_nt_dma_w<EPI, NT16, PK, 2>(A, B, ldb, M, N, K, ep, stream);
   return launch_nt_dma_w<EPI, NT16, PK, 4>(A, B, ldb, M, N, K, ep, stream);
 }
 
@@ -1991,6 +1993,45 @@ __global__ __launch_bounds__(256) void seq_list_kernel(const int32_t* __restrict
   }
 }
 }  // namespace
+// Forward: the sequences whose output somebody needs (flags[i] != 0), and exact zeros in the y rows of the others.
+namespace {
+__global__ __launch_bounds__(256) void needed_list_kernel(const int32_t* __restrict__ flags, int n, int32_t* __restrict__ count,
+                                                          int32_t* __restrict__ list) {
+  __shared__ int wave_cnt[4];
+  __shared__ int base;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i = blockIdx.x * 256 + tid;
+  const bool keep = i < n && flags[i] != 0;
+  const uint64_t bal = __ballot(keep);
+  if (lane == 0) wave_cnt[wid] = __popcll(bal);
+  __syncthreads();
+  if (tid == 0) base = atomicAdd(count, wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
+  __syncthreads();
+  if (keep) {
+    int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wid; ++w) pos += wave_cnt[w];
+    list[pos] = i;
+  }
+}
+// one workgroup per unneeded sequence: its rows (chunks16 16-byte pieces) become zeros
+__global__ __launch_bounds__(256) void zero_unneeded_kernel(const int32_t* __restrict__ flags, uint4* __restrict__ y, int chunks16) {
+  const int seq = blockIdx.x;
+  if (flags[seq] != 0) return;
+  uint4* p = y + (size_t)seq * chunks16;
+  for (int c = threadIdx.x; c < chunks16; c += 256) p[c] = make_uint4(0, 0, 0, 0);
+}
+}  // namespace
+// out: int32 [4 + n]: out[0] = count, out[4 ..] = the needed sequences; y rows of the others are zero-filled (row_bytes % 16 == 0)
+int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream) {
+  NR_CHECK_ARG(flags != nullptr && out != nullptr && y != nullptr && seq_bytes % 16 == 0 && (((uintptr_t)y) & 15) == 0, "needed_list: bad arguments");
+  NR_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream));
+  NrProfScope ps(stream, "needed_list[n=%d]", n);
+  hipLaunchKernelGGL(needed_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, flags, n, out, out + 4);
+  hipLaunchKernelGGL(zero_unneeded_kernel, dim3(n), dim3(256), 0, stream, flags, reinterpret_cast<uint4*>(y), (int)(seq_bytes / 16));
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
 // out: int32 [4 + n]: out[0] = count, out[4 ..] = sequence numbers
 int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream) {
   NR_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream));

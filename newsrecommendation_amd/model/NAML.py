@@ -34,16 +34,19 @@ class NewsEncoder(nn.Module):
         self.cnn = nn.Conv1d(in_channels=args.word_embedding_dim, out_channels=args.news_dim, kernel_size=3, padding=1)
         self.attn = AttentionPooling(args.news_dim, args.news_query_vector_dim, compute_dtype=_cd(args))
 
-    def forward(self, x, mask=None):
-        """x: [n, F] int32, columns = [news id, category id, subcategory id][:F] -> [n, news_dim] fp32."""
+    def forward(self, x, mask=None, needed=None):
+        """x: [n, F] int32, columns = [news id, category id, subcategory id][:F] -> [n, news_dim] fp32.
+        needed (beyond the reference): optional [n] flags; 0 = the caller multiplies this news vector by zero (a masked history
+        slot): its title view is not encoded (zeros)."""
         code = ops.dtype_code(self.compute_dtype)
         if x.dtype != torch.int32:
             x = x.to(torch.int32)
         x = x.contiguous()
         p = self.drop_rate if self.training else 0.0
+        needed = ops.needed_flags(needed)
         ctx = ops.conv1d_k3_gather(self.title_embeddings.weight, self.cnn.weight, self.cnn.bias, x[:, 0],
-                                   self.num_words_title, self.word_embedding_dim, code, p_in=p)
-        all_vecs = [self.attn(ctx, mask)]
+                                   self.num_words_title, self.word_embedding_dim, code, p_in=p, needed=needed)
+        all_vecs = [self.attn(ctx, mask, needed=needed)]
         col = 1
         if self.use_category:
             all_vecs.append(ops.gather_linear(self.category_emb.weight, self.category_dense.weight,
@@ -90,7 +93,10 @@ class Model(torch.nn.Module):
         a = self.args
         F = history.shape[-1]
         B, C = candidate.shape[0], 1 + a.npratio
-        vecs = self.news_encoder(torch.cat([candidate.reshape(-1, F), history.reshape(-1, F)], dim=0))
+        needed = None                                  # masked history slots reach the loss through a factor 0 (NAML.py:92-96)
+        if not getattr(a, "encode_masked_slots", False):
+            needed = torch.cat([history_mask.new_ones(B * C), history_mask.reshape(-1)])
+        vecs = self.news_encoder(torch.cat([candidate.reshape(-1, F), history.reshape(-1, F)], dim=0), needed=needed)
         cand_flat, hist_flat = vecs.split([B * C, vecs.shape[0] - B * C], dim=0)     # one cat in backward, no zero fills
         cand_vecs = cand_flat.reshape(B, C, a.news_dim)
         hist_vecs = hist_flat.reshape(B, a.user_log_length, a.news_dim)

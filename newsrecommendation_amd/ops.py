@@ -628,7 +628,7 @@ class ConvFunction(Function):
         x_rows = torch.empty(n * T, 3 * Dp, dtype=torch.bfloat16, device=dev) if code == _lib.NR_BF16 and n > 0 else None
         d = _lib.ConvDesc(n=n, T=T, D=D, Dp=Dp, N=N, dtype=code, table=ptr(table_p), ids=ids.data_ptr(), ids_stride=stride,
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], w_pack=ptr(w_p), bias=ptr(b_c), x_rows=ptr(x_rows),
-                          ld_rows=3 * Dp)
+                          ld_rows=3 * Dp, seq_needed=ptr(cfg.get("needed")))
         check(_lib.lib().nr_conv1d_k3_fwd(C.byref(d), ptr(y), _stream()), "nr_conv1d_k3_fwd")
         ctx.cfg, ctx.dims = cfg, (n, T, D, Dp, N, stride)
         ctx.ids = ids                                   # keeps the (possibly strided) id view alive
@@ -663,15 +663,17 @@ class ConvFunction(Function):
         return dw, db, None, None
 
 
-def conv1d_k3_gather(table, w, b, ids, T: int, D: int, code: int, p_in=0.0):
-    """ids: int32 view [n] (any stride) of news ids; table: fp32 [V, T*D] (frozen on this path)."""
+def conv1d_k3_gather(table, w, b, ids, T: int, D: int, code: int, p_in=0.0, needed=None):
+    """ids: int32 view [n] (any stride) of news ids; table: fp32 [V, T*D] (frozen on this path).
+    needed: optional [n] int32 flags (needed_flags); output rows of unneeded titles may stay unwritten -- pool them with the
+    same flags."""
     if table.requires_grad:
         raise RuntimeError("NAML title-embedding table must be frozen (freeze_embedding=True, as src/demo.sh:12): "
                            "its [V, T*D] dense gradient is out of scope on this path")
     if CHECK_INDICES:
         check_ids(ids, table.shape[0], "news id")
     cfg = dict(code=code, T=T, D=D, p_in=float(p_in), seed_in=draw_seed() if p_in > 0 else 0,
-               table_packed=table_cache.get(table, code, row_cols=D))
+               table_packed=table_cache.get(table, code, row_cols=D), needed=needed)
     return ConvFunction.apply(w, b, ids, cfg)
 
 

@@ -94,7 +94,7 @@ def test_nrms_b128_every_gradient_against_the_oracle(dt, train):
         ops.POISON_WORKSPACES = False
     if dt == "bf16":
         # the kernels of the benchmarked step, not their small-shape stand-ins
-        for want in ("gemm_tn3_live", "attn_mfma_bwd_live", "gemm_nt_dma_live", "attn_mfma_fwd", "pool_core_bwd"):
+        for want in ("gemm_tn3_live", "attn_mfma_bwd_live", "gemm_nt_dma_live", "attn_mfma_fwd_live", "needed_list", "pool_core_bwd"):
             assert _has(labels, want), (want, sorted(labels))
     if train:
         n, T, D, N, p = B * 55, cfg.num_words_title, cfg.word_embedding_dim, cfg.news_dim, cfg.drop_rate
