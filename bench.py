@@ -114,7 +114,7 @@ def batch_structure(batches, args, model_name):
     share of token rows with a non-padding id (`*_live` NT GEMMs), share of 32-row slabs that touch a title with a
     non-zero upstream gradient (`gemm_tn3_live`), share of sequences the attention backward walks."""
     T = args.num_words_title
-    live_rows, live_slabs, live_seq, live_titles, needed = [], [], [], [], []
+    live_rows, live_slabs, live_seq, live_titles, needed, needed_tiles = [], [], [], [], [], []
     for hist, mask, cand, _ in batches:
         B, H = mask.shape
         C = cand.shape[1]
@@ -133,10 +133,13 @@ def batch_structure(batches, args, model_name):
         pad = (-M) % 32
         slab_nz = torch.nn.functional.pad(row_nz, (0, pad)).view(-1, 32).amax(1)
         live_slabs.append(float(slab_nz.mean()))
+        tile_nz = torch.nn.functional.pad(row_nz, (0, (-M) % 128)).view(-1, 128).amax(1)
+        needed_tiles.append(float(tile_nz.mean()))
         near = torch.nn.functional.max_pool1d(nz_title[None, None], kernel_size=7, stride=1, padding=3)[0, 0] > 0
         live_seq.append(float((~(allpad & ~near)).float().mean()))
     avg = lambda x: sum(x) / len(x)
     return {"live_token_rows": round(avg(live_rows), 4), "live_titles": round(avg(live_titles), 4), "needed_titles": round(avg(needed), 4),
+            "needed_tiles": round(avg(needed_tiles), 4),
             "live_gradient_slabs": round(avg(live_slabs), 4), "attention_bwd_sequences": round(avg(live_seq), 4)}
 
 
@@ -158,6 +161,8 @@ def price_kernel(label, avg_ms, struct, dtype):
         M, N, K = d
         if name.endswith("_live"):
             M = M * (struct["live_gradient_slabs"] if name.startswith("gemm_tn") else struct["live_token_rows"])
+        elif name.endswith("_needed"):
+            M = M * struct.get("needed_tiles", 1.0)              # row tiles with at least one needed title
         fl = 2.0 * M * N * K
         peak = PEAK_MFMA_BF16 if "bf16" in label else PEAK_MFMA_F32
         return {"bound": "mfma", "achieved": round(fl / s / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "work": fl}
@@ -418,7 +423,7 @@ def run_eval(a, args, device, rank, world, dist_on):
     if rank != 0:
         return
     sums = sums.cpu().tolist()
-    struct = {"live_token_rows": float((comb != 0).mean()), "live_titles": 1.0, "needed_titles": 1.0, "live_gradient_slabs": 1.0,
+    struct = {"live_token_rows": float((comb != 0).mean()), "live_titles": 1.0, "needed_titles": 1.0, "needed_tiles": 1.0, "live_gradient_slabs": 1.0,
               "attention_bwd_sequences": 1.0}
     out = {"metric": "eval impressions/sec (full-corpus encode + scoring + ranking metrics), NRMS", "value": round(n * world * a.steps / dt, 1),
            "unit": "impressions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),

@@ -1869,8 +1869,11 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
   if (dense_bf16 && !no_dma && K >= dma_min_k && ldb >= kr32 && A.ld >= K) {
     // B must be zero beyond K up to the next multiple of 32 (nr_cast_pad with such an ld guarantees it)
     // with row compaction only the live rows (count on the device) are multiplied: M is then an upper bound
-    NrProfScope ps(stream, ep.row_count ? "gemm_nt_dma_live[bf16,epi=%d,Mmax=%d,N=%d,K=%d]" : "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d]", epi,
-                   M, N, K);
+    // "_live": rows compacted on the device; "_needed": row tiles of unneeded sequences are skipped (M is an upper bound in both)
+    const bool tile_skip = (epi == EPI_STORE || epi == EPI_STORE_TANH) && ep.seq_nz != nullptr && ep.row_count == nullptr;
+    NrProfScope ps(stream, ep.row_count ? "gemm_nt_dma_live[bf16,epi=%d,Mmax=%d,N=%d,K=%d]"
+                                        : (tile_skip ? "gemm_nt_dma_needed[bf16,epi=%d,Mmax=%d,N=%d,K=%d]" : "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d]"),
+                   epi, M, N, K);
     const int c13 = ((N + 207) / 208) * 13, c20 = ((N + 319) / 320) * 20;   // fewer padded column tiles wins
     if (c13 < c20) return launch_nt_dma_e<13>(A, B, ldb, M, N, K, epi, ep, stream);
     return launch_nt_dma_e<20>(A, B, ldb, M, N, K, epi, ep, stream);
