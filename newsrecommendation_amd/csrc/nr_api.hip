@@ -12,6 +12,7 @@ int nr_launch_attn(bool bwd, int dtype, const void* qkv, const float* mask, void
                    const float* bias = nullptr, const int32_t* seq_list = nullptr, const int32_t* seq_count = nullptr,
                    const int32_t* needed = nullptr);
 bool nr_attn_pad_ok(int dtype, int L, int d_head, const void* p0, const void* p1);
+bool nr_attn_rowsub_ok(int dtype, int L, int d_head, int heads);
 int nr_launch_attn_gather_fwd(const void* proj_table, const int32_t* ids, const float* mask, void* y, int n, int L, int heads,
                               int d_head, const DropCfg& drop, hipStream_t stream);
 int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
@@ -41,7 +42,7 @@ struct OptDef { const char* name; int def; };
 const OptDef g_opt_defs[NR_OPT_COUNT] = {
     {"NO_SLABS", 0},   {"NO_ATTN_SKIP", 0}, {"SIDE_STREAM", 0}, {"ATTN_OLD", 0},  {"ATTN_VALU", 0},   {"NO_PAD_SUB", 0},
     {"NO_FUSED_FWD", 0}, {"NO_TN3", 0},     {"TN_V1", 0},       {"TN3_ROUNDS", 0}, {"TN3_WK", 0},      {"TN3_NI", 0},
-    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}};
+    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}, {"NO_ROW_SUB", 0}, {"ATTN_BWD_OCC4", 0}};
 std::atomic<int> g_opt[NR_OPT_COUNT];
 std::once_flag g_opt_once;
 void opt_init() {
@@ -478,7 +479,9 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
       // neither written here nor read there.  The bias goes into the padding rows of the other sequences.
       if (d->b_qkv != nullptr && nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, y))
         tmask = reinterpret_cast<const uint32_t*>(d->row_ws + W.tmask);
-      if ((rc = nr_launch_bias_rows(qkv, 3 * N, 3 * N, d->b_qkv, d->row_ws + W.dead_idx, d->row_ws + 1, M, tmask, d->L, s)))
+      // ... unless the attention kernels substitute per row (then no padding row of qkv is ever written or read)
+      if (!(tmask != nullptr && nr_attn_rowsub_ok(d->dtype, d->L, d->d_head, d->heads)) &&
+          (rc = nr_launch_bias_rows(qkv, 3 * N, 3 * N, d->b_qkv, d->row_ws + W.dead_idx, d->row_ws + 1, M, tmask, d->L, s)))
         return rc;
     }
   }

@@ -641,6 +641,28 @@ __device__ __forceinline__ void panel_store_all(const bf16_t* panel, int ops, bf
   for (int t = 0; t < PT; ++t)
     *reinterpret_cast<bf16x4*>(dst + (uint32_t)(pc.row(t) * ld + pc.q4(t))) = *reinterpret_cast<const bf16x4*>(panel + pc.row(t) * ops + pc.q4(t));
 }
+// Per-ROW padding substitution (FULL kernels with a live-token mask tm of the sequence): a padding token's Q|K|V row is the
+// bias, so its row of the qkv buffer is never written by the projection and never read here -- the load goes to row 0 of
+// the buffer instead (an L2 hit, value ignored) and the LDS image gets the bias piece.
+template <int PT>
+__device__ __forceinline__ void panel_load_sub(Panel<PT>& r, const bf16_t* __restrict__ buf, uint32_t seq_off, int coff, int ld,
+                                               const Pieces<PT>& pc, uint32_t tm) {
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const uint32_t row = (uint32_t)pc.row(t);
+    const uint32_t off = (((tm >> row) & 1u) ? seq_off + row * (uint32_t)ld : 0u) + (uint32_t)(coff + pc.q4(t));
+    r.v[t] = *reinterpret_cast<const bf16x4*>(buf + (size_t)off);
+  }
+}
+template <int PT>
+__device__ __forceinline__ void panel_put_sub(const Panel<PT>& r, bf16_t* img0, const Pieces<PT>& pc, const bf16_t* sbias, uint32_t tm) {
+#pragma unroll
+  for (int t = 0; t < PT; ++t) {
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(sbias + pc.q4(t));
+    const bf16x4 v = ((tm >> (uint32_t)pc.row(t)) & 1u) ? r.v[t] : b;
+    *reinterpret_cast<bf16x4*>(img0 + pc.loff(t)) = v;
+  }
+}
 // row-indirect variant: token row r of the sequence lives at table row ids[r] (ids points at the sequence's first token)
 template <int PT>
 __device__ __forceinline__ void panel_load_g(Panel<PT>& r, const bf16_t* __restrict__ table, int ld, const int32_t* __restrict__ ids,
@@ -756,6 +778,8 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   Panel<PT> rq, rk, rv;
   bool dead_next = false;                                // the item sitting in rq / rk / rv is all padding
   bool dead_seq = false;                                 // ... of the sequence the prefetcher is in
+  constexpr bool ROWSUB = FULL && SUB && !GATHER;        // per-row padding substitution (see panel_load_sub)
+  uint32_t tm_seq = 0, tm_item = 0;                      // live-token mask of the prefetcher's sequence / of the prefetched item
   const bool has_needed = a.needed != nullptr;
   bool skip_seq = false, skip_next = false, skip_cur = false;   // nobody uses the sequence's output: zeros are stored, nothing is computed
   auto prefetch = [&](const ItemIter& t) {
@@ -764,8 +788,10 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
     if (t.hg == 0 || !FULL) {
       const int sbu = __builtin_amdgcn_readfirstlane(t.sb);
       sq_next = !listed ? sbu : (FULL ? (int)sload_u32(a.seq_list + sbu) : a.seq_list[sbu]);
-      if (SUB)                                           // a sequence of padding tokens only: Q|K|V = bias, nothing to load
-        dead_seq = (FULL ? sload_u32(a.tmask + sq_next) : a.tmask[sq_next]) == 0;
+      if (SUB) {                                         // a sequence of padding tokens only: Q|K|V = bias, nothing to load
+        tm_seq = FULL ? sload_u32(a.tmask + sq_next) : a.tmask[sq_next];
+        dead_seq = tm_seq == 0;
+      }
       if (has_needed) skip_seq = (FULL ? sload_u32(a.needed + sq_next) : (uint32_t)a.needed[sq_next]) == 0;
     }
     skip_next = has_needed && skip_seq;
@@ -775,6 +801,12 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
       panel_load_g(rq, qkv, N3, idp, hoff, pc, hcount);
       panel_load_g(rk, qkv, N3, idp, N + hoff, pc, hcount);
       panel_load_g(rv, qkv, N3, idp, 2 * N + hoff, pc, hcount);
+    } else if (ROWSUB) {
+      tm_item = skip_next ? 0u : tm_seq;                 // a skipped sequence loads nothing real either
+      const uint32_t so = (uint32_t)sq_next * (uint32_t)(L * N3);
+      panel_load_sub(rq, qkv, so, hoff, N3, pc, tm_item);
+      panel_load_sub(rk, qkv, so, N + hoff, N3, pc, tm_item);
+      panel_load_sub(rv, qkv, so, 2 * N + hoff, N3, pc, tm_item);
     } else if (FULL) {
       const bf16_t* src = qkv + (dead_next ? (size_t)0 : (size_t)sq_next * L * N3) + hoff;   // dead: any valid rows (L2 hits), ignored
       panel_load_all(rq, src, N3, pc);
@@ -791,7 +823,12 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
   // put: the item sitting in the prefetch registers goes into the LDS images (waits for its loads)
   auto put = [&](const ItemIter& t) {
-    if (SUB && dead_next) {
+    if (ROWSUB) {
+      const int hoff = t.hg * AW * d;
+      panel_put_sub(rq, img0, pc, sBias + hoff, tm_item);
+      panel_put_sub(rk, img0 + IMG, pc, sBias + N + hoff, tm_item);
+      panel_put_sub(rv, img0 + 2 * IMG, pc, sBias + 2 * N + hoff, tm_item);
+    } else if (SUB && dead_next) {
       const int hoff = t.hg * AW * d, hcount = min(AW, heads - t.hg * AW);
       panel_put_bias<PT, FULL>(img0, pc, sBias + hoff, hcount);
       panel_put_bias<PT, FULL>(img0 + IMG, pc, sBias + N + hoff, hcount);
@@ -861,10 +898,11 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   }
 }
 
-template <bool HAS_MASK, int PT, bool SUB, bool FULL = false, int LC = 0, int DC = 0, int HC = 0>
-// the shape-specialised instantiation fits 128 VGPRs (4 waves per SIMD: 0.75 -> 0.71 ms); the generic ones need ~160 and
-// would spill under that cap (1.6 - 2.3 ms)
-__global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(LC ? 4 : 3, LC ? 4 : 3))) void bwd_kernel(AttnMArgs a) {
+template <bool HAS_MASK, int PT, bool SUB, bool FULL = false, int LC = 0, int DC = 0, int HC = 0, int OCC = 3>
+// OCC = waves per SIMD the register allocation aims at.  The generic instantiations need ~160 VGPRs and spill heavily under a
+// 128 cap (1.6 - 2.3 ms instead of 0.75); the shape-specialised one fitted 128 before the per-row padding substitution and
+// spills a little with it -- 3 waves without spills win (NR_ATTN_BWD_OCC4 keeps the other build selectable)
+__global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void bwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR address math
   // Image block, MATRIX-major: [Q x AW waves | V x AW | K x AW | G x AW].  The output panels of an item are written over
@@ -899,12 +937,17 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(LC ? 4 
   // FULL (see fwd_kernel): the sequence number and its padding flag come through the scalar cache once per sequence, every
   // thread issues the same 4 * PT loads and 3 * PT stores per item, so no wait in the loop is a vmcnt(0)
   bool dead_seq = false;
+  constexpr bool ROWSUB = FULL && SUB;                   // per-row padding substitution (see panel_load_sub)
+  uint32_t tm_seq = 0;                                   // live-token mask of the prefetcher's sequence
   auto prefetch = [&](const ItemIter& t) {
     if (FULL) {
       if (t.hg == 0) {
         const int sbu = __builtin_amdgcn_readfirstlane(t.sb);
         sq_next = listed ? (int)sload_u32(a.seq_list + sbu) : sbu;
-        if (SUB) dead_seq = sload_u32(a.tmask + sq_next) == 0;
+        if (SUB) {
+          tm_seq = sload_u32(a.tmask + sq_next);
+          dead_seq = tm_seq == 0;
+        }
       }
     } else {
       sq_next = listed ? a.seq_list[t.sb] : t.sb;
@@ -915,7 +958,13 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(LC ? 4 
     const int hd = t.hg * AW * d;
     const int hcount = min(AW, heads - t.hg * AW);
     dead_next = SUB && dead_seq;
-    if (FULL) {
+    if (ROWSUB) {
+      const uint32_t so = (uint32_t)sq * (uint32_t)(L * N3);
+      panel_load_sub(rq, qkv, so, hd, N3, pc, tm_seq);
+      panel_load_sub(rk, qkv, so, N + hd, N3, pc, tm_seq);
+      panel_load_sub(rv, qkv, so, 2 * N + hd, N3, pc, tm_seq);
+      panel_load_all(rg, dy + r0 * N + hd, N, pc);
+    } else if (FULL) {
       const bf16_t* src = qkv + (dead_next ? (size_t)0 : r0 * N3) + hd;   // dead: any valid rows (L2 hits), ignored
       panel_load_all(rq, src, N3, pc);
       panel_load_all(rk, src + N, N3, pc);
@@ -936,7 +985,12 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(LC ? 4 
   // put: the item sitting in the prefetch registers (sequence sq_next) goes into the LDS images
   auto put = [&](const ItemIter& t) {
     const size_t r0 = (size_t)sq_next * L;
-    if (SUB && dead_next) {
+    if (ROWSUB) {                                        // tm_seq still belongs to the prefetched item: put follows its prefetch
+      const int hoff = t.hg * AW * d;
+      panel_put_sub(rq, imQ, pc, sBias + hoff, tm_seq);
+      panel_put_sub(rk, imK, pc, sBias + N + hoff, tm_seq);
+      panel_put_sub(rv, imV, pc, sBias + 2 * N + hoff, tm_seq);
+    } else if (SUB && dead_next) {
       const int hoff = t.hg * AW * d, hcount = min(AW, heads - t.hg * AW);
       panel_put_bias<PT, FULL>(imQ, pc, sBias + hoff, hcount);
       panel_put_bias<PT, FULL>(imK, pc, sBias + N + hoff, hcount);
@@ -1475,12 +1529,15 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(AW * 64), smem_s, stream, a); };
   // FULL: all head slots real and the store panels alias the images (d <= 21 in the backward): unpredicated memory
   // instructions, counted waits (see fwd_kernel)
-  const bool full = a.heads % AW == 0 && a.L * a.d >= 64 && (!bwd || 3 * 32 * AW * a.d <= 2 * AW * IMG) && !nr_opt(NR_OPT_ATTN_PRED);
+  // (the forward takes the backward's shape condition too: both directions must agree on who supplies padding rows)
+  const bool full = a.heads % AW == 0 && a.L * a.d >= 64 && 3 * 32 * AW * a.d <= 2 * AW * IMG && !nr_opt(NR_OPT_ATTN_PRED);
   const bool title30 = full && p3 && a.L == 30 && a.d == 20 && a.heads == 20 && !nr_opt(NR_OPT_ATTN_GENERIC);   // the reference's defaults
   auto pick = [&](auto tag_mask, auto tag_sub) {
     constexpr bool HM = decltype(tag_mask)::value, SB = decltype(tag_sub)::value;
     if (bwd) {
-      if (title30) go(bwd_kernel<HM, 3, SB, true, 30, 20, 20>);
+      // 3 waves per SIMD without spills beat 4 with the 11 scratch accesses per item the row substitution pushes the
+      // 128-VGPR build into (same box: 0.74 vs 0.91 ms)
+      if (title30) nr_opt(NR_OPT_ATTN_BWD_OCC4) ? go(bwd_kernel<HM, 3, SB, true, 30, 20, 20, 4>) : go(bwd_kernel<HM, 3, SB, true, 30, 20, 20, 3>);
       else if (full) p3 ? go(bwd_kernel<HM, 3, SB, true>) : go(bwd_kernel<HM, 4, SB, true>);
       else p3 ? go(bwd_kernel<HM, 3, SB>) : go(bwd_kernel<HM, 4, SB>);
     } else if (!SB && a.ids != nullptr) {
@@ -1565,6 +1622,13 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   return dtype == NR_BF16 ? launch_t<bf16_t>(bwd, a, stream) : launch_t<float>(bwd, a, stream);
 }
 
+
+// True when the bf16 panel kernels substitute the bias for padding ROWS themselves (FULL + live-token masks): the projection
+// then need not write the bias into the padding rows of partly live sequences (nr_launch_bias_rows), nobody reads them.
+bool nr_attn_rowsub_ok(int dtype, int L, int d_head, int heads) {
+  return dtype == NR_BF16 && nr_attn_pad_ok(dtype, L, d_head, nullptr, nullptr) && heads % AW == 0 && L * d_head >= 64 &&
+         3 * 32 * AW * d_head <= 2 * AW * b16::IMG && !nr_opt(NR_OPT_ATTN_PRED) && !nr_opt(NR_OPT_NO_ROW_SUB);
+}
 
 // Forward attention whose Q|K|V rows are gathered from a per-token-id table of projections [V, 3N] (bf16 panel kernel:
 // L <= 32, d_head % 4 == 0, 8-byte aligned).  Returns -1 when the shape has no such kernel.

@@ -90,6 +90,8 @@ enum NrOpt {
   NR_OPT_DMA_WM2_ALL,    // 1: 128-row DMA tiles for every N
   NR_OPT_ATTN_PRED,      // 1: predicated (pre-"FULL") memory instructions in the bf16 panel attention kernels
   NR_OPT_ATTN_GENERIC,   // 1: no shape-specialised (L=30, 20 heads of 20) instantiation of the panel attention kernels
+  NR_OPT_NO_ROW_SUB,     // 1: the projection writes the bias into padding rows (bias_rows) instead of per-row substitution
+  NR_OPT_ATTN_BWD_OCC4,  // 1: the specialised attention backward built for 4 waves per SIMD (128 VGPRs, a few spills) instead of 3
   NR_OPT_COUNT
 };
 int nr_opt(int which);
