@@ -160,3 +160,58 @@ def test_naml_b128_every_gradient_against_the_oracle(dt, train):
     worst = _grad_report(m, {k: v.grad for k, v in sdo.items() if v.grad is not None}, t["gatol"], t["grtol"])
     print(f"naml B={B} {dt} train={train}: worst grad err / max|g|: "
           + ", ".join(f"{k.split('.', 1)[1]}={v:.2e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]))
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_needed_flags_change_nothing_observable(train):
+    """`Model.forward` tells the news encoder which history slots are masked (their vectors reach the loss through a factor 0);
+    the kernels then skip them.  Against `args.encode_masked_slots=True` (every title encoded, as the reference does): the same
+    loss, scores and gradients -- dropout counters keep the original element indices, so training mode draws the same masks.
+    What differs is the order of fp32 atomics only."""
+    outs = []
+    for encode_all in (True, False):
+        cfg, sd, m, (hist, mask, cand, label) = _nrms_case("bf16", 60)
+        m.args.encode_masked_slots = encode_all
+        m.train(train)
+        torch.manual_seed(777)
+        loss, score = m(hist.cuda(), mask.cuda(), cand.cuda(), label.cuda())
+        loss.backward()
+        outs.append((loss.detach().clone(), score.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    (l0, s0, g0), (l1, s1, g1) = outs
+    assert torch.equal(s0, s1) and torch.equal(l0, l1)            # forward: bit-identical
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * float(g0[k].abs().max()) + 1e-8, k
+
+
+def test_flat_bucket_over_rccl_single_rank():
+    """parallel.FlatBucket on the 'nccl' (= RCCL) backend with one rank: broadcast, the flat all-reduce and the fused Adam run
+    against the package's autograd Functions writing straight into the bucket; with a single rank the step must equal the
+    plain one (same seeds -> same dropout draws)."""
+    import os
+    import torch.distributed as dist
+    from newsrecommendation_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        res = []
+        for _ in range(2):
+            cfg, sd, m, (hist, mask, cand, label) = _nrms_case("bf16", 70)
+            m.train()
+            fb = parallel.FlatBucket(m, lr=1e-3)
+            assert fb.world == 1 or dist.get_world_size() == 1
+            torch.manual_seed(5)
+            loss, _ = m(hist.cuda(), mask.cuda(), cand.cuda(), label.cuda())
+            loss.backward()
+            g = fb.grad.clone()
+            fb.allreduce()                                     # RCCL all_reduce over the flat buffer (a copy with one rank)
+            assert torch.equal(g, fb.grad)
+            fb.adam_step()
+            res.append((float(loss), fb.param.clone()))
+        assert res[0][0] == res[1][0]
+        # two identical runs: parameters agree up to the order of the fp32 atomics in the gradients (Adam's first step is
+        # +-lr * sign-like, so compare where the gradient is not noise)
+        diff = (res[0][1] - res[1][1]).abs()
+        assert float((diff > 1.5e-3).float().mean()) < 1e-3
+    finally:
+        dist.destroy_process_group()
