@@ -458,6 +458,8 @@ def main():
                          "from news-index arrays (train.DeviceFeed, SURVEY §8 row f1)")
     ap.add_argument("--dp-mode", default="flat", choices=["flat", "ddp"],
                     help="flat: parallel.FlatBucket (one all-reduce + fused HIP Adam); ddp: DistributedDataParallel + torch.optim.Adam")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="ops.set_deterministic(True): fixed-point integer-atomic gradient accumulation (bit-reproducible gradients)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--compact-history", action="store_true",
@@ -508,6 +510,9 @@ def main():
         table[0] = 0
         model = NAML.Model(args, table.numpy(), 17, 264).to(device)
     model.train()
+    if a.deterministic:
+        from newsrecommendation_amd import ops as _ops
+        _ops.set_deterministic(True, elements=sum(p.numel() for p in model.parameters()) + (1 << 20), device=device)
     net, bucket, opt = model, None, None
     if a.dp_mode == "flat":
         bucket = parallel.FlatBucket(model, lr=1e-4)       # rank-0 broadcast; per step ONE all-reduce + ONE fused Adam kernel
@@ -593,6 +598,7 @@ def main():
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "vocab_rows": a.vocab,
                           "dropout": args.drop_rate, "freeze_embedding": args.freeze_embedding,
                           "compact_history": bool(a.compact_history), "dense_batch": bool(a.dense_batch), "feed": a.feed,
+                          "deterministic": bool(a.deterministic),
                           "optimizer": "flat bucket + HIP fused Adam" if bucket is not None else "DDP + torch.optim.Adam(fused)",
                           "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "batch_structure": struct}}
         out["roofline"] = roofline_of(prof, a.dtype, struct)

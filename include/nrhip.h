@@ -56,6 +56,14 @@ int nr_last_error(char* buf, size_t n);
 /* sizeof of the descriptor structs as this library was compiled: out[0..3] = nr_mhsa_desc, nr_conv_desc, nr_pool_desc,
  * nr_linear_desc.  A binding compares them with its own layout at load time (ABI drift -> refuse to run).            */
 int nr_abi_sizes(size_t* out, int n);
+/* Deterministic mode.  Outputs that several workgroups add into (dW, db, dtable, dpad) are accumulated with fp32 atomics
+ * by default, so their last bits depend on the arrival order.  With a scratch buffer registered here they are accumulated
+ * in 2^-36 fixed point with 64-bit integer atomics (order independent) and flushed onto the fp32 output at the end of
+ * each call: gradients are bit-reproducible from run to run.  scratch: DEVICE memory, ZERO filled, 8 bytes per element of
+ * the largest set of accumulated outputs of one call (e.g. 3N*(d_model+1) + table_rows*d_model for nr_mhsa_bwd); the
+ * library leaves it zero filled after every call.  scratch == NULL switches the mode off.  One stream at a time.
+ * Gather sources need `table_rows` in their descriptor in this mode.                                               */
+int nr_set_deterministic(void* scratch, size_t bytes);
 int nr_set_option(const char* name, int value);
 int nr_get_option(const char* name);
 
@@ -126,6 +134,7 @@ typedef struct {
                          (their dQ|dK|dV rows stay unwritten and are never read).  No host synchronisation.  NULL: every row
                          goes through the GEMMs.                    */
   size_t row_ws_bytes; /* size of row_ws in bytes: must be >= nr_mhsa_workspace_bytes(d) when row_ws != NULL (checked) */
+  int table_rows;     /* gather source: rows V of the table (needed in deterministic mode only, to size dtable's shadow; else 0) */
   const void* proj_table; /* nr_mhsa_fwd only, optional [V, 3N] dtype = table . W_qkv^T + b_qkv (one nr_gemm_nt over the table):
                          eval mode (p_in == 0, bf16 gather source, qkv == NULL, no backward) gathers the projections of a token
                          from here instead of projecting every occurrence -- same values, ~V/(n*L) of the GEMM work */
@@ -267,6 +276,7 @@ typedef struct {
   const void* w_t;   /* [K, ldwt] dtype = w^T; only read by nr_linear_bwd when dtable != NULL */
   int ldwt;
   size_t dout_ws_bytes; /* nr_linear_bwd: size of dout_ws in bytes, >= nr_linear_workspace_bytes(d) (checked) */
+  int table_rows;    /* gather source: rows V of the table (deterministic mode only, see nr_set_deterministic; else 0) */
 } nr_linear_desc;
 size_t nr_linear_workspace_bytes(const nr_linear_desc* d);
 int nr_linear_fwd(const nr_linear_desc* d, float* out, int ld_out, nr_stream_t stream);

@@ -28,7 +28,7 @@ class MhsaDesc(C.Structure):
                 ("p_in", C.c_float), ("seed_in", C.c_uint32), ("p_out", C.c_float), ("seed_out", C.c_uint32),
                 ("mask", C.c_void_p), ("w_qkv", C.c_void_p), ("ldw", C.c_int), ("b_qkv", C.c_void_p),
                 ("x_rows", C.c_void_p), ("ld_rows", C.c_int), ("row_ws", C.c_void_p), ("row_ws_bytes", C.c_size_t),
-                ("proj_table", C.c_void_p), ("seq_needed", C.c_void_p), ("seq_nz", C.c_void_p), ("row_ws_ready", C.c_int)]
+                ("table_rows", C.c_int), ("proj_table", C.c_void_p), ("seq_needed", C.c_void_p), ("seq_nz", C.c_void_p), ("row_ws_ready", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -48,7 +48,7 @@ class PoolDesc(C.Structure):
 class LinearDesc(C.Structure):
     _fields_ = [("M", C.c_int), ("K", C.c_int), ("N", C.c_int), ("dtype", C.c_int), ("src_kind", C.c_int),
                 ("x", C.c_void_p), ("ldx", C.c_int), ("ids", C.c_void_p), ("ids_stride", C.c_int), ("w", C.c_void_p),
-                ("ldw", C.c_int), ("bias", C.c_void_p), ("w_t", C.c_void_p), ("ldwt", C.c_int), ("dout_ws_bytes", C.c_size_t)]
+                ("ldw", C.c_int), ("bias", C.c_void_p), ("w_t", C.c_void_p), ("ldwt", C.c_int), ("dout_ws_bytes", C.c_size_t), ("table_rows", C.c_int)]
 
 
 _vp, _i, _f, _u32 = C.c_void_p, C.c_int, C.c_float, C.c_uint32
@@ -59,6 +59,7 @@ SIGNATURES = {
     "nr_version": [],
     "nr_last_error": [C.c_char_p, C.c_size_t],
     "nr_abi_sizes": [C.POINTER(C.c_size_t), _i],
+    "nr_set_deterministic": [_vp, C.c_size_t],
     "nr_set_option": [C.c_char_p, _i],
     "nr_get_option": [C.c_char_p],
     "nr_mhsa_workspace_bytes": [C.POINTER(MhsaDesc)],

@@ -126,6 +126,89 @@ void nr_set_error(const char* fmt, ...) {
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// ---- deterministic mode (nr_set_deterministic, nr_common.h: NrFixTable) ------------------------------------------
+namespace {
+std::atomic<long long*> g_det_ws{nullptr};
+std::atomic<size_t> g_det_elems{0};
+// Host copies of the range table must outlive the asynchronous symbol copies: a small per-thread ring.
+thread_local NrFixTable g_fix_ring[64];
+thread_local int g_fix_pos = 0;
+struct DetScope {
+  NrFixTable* t = nullptr;
+  hipStream_t s;
+  size_t used = 0;
+  bool gemm = false, pool = false, begun = false;
+  int rc = NR_OK;
+  explicit DetScope(hipStream_t stream) : s(stream) {
+    if (g_det_ws.load() != nullptr) {
+      t = &g_fix_ring[g_fix_pos];
+      g_fix_pos = (g_fix_pos + 1) & 63;
+      memset(t, 0, sizeof(*t));
+    }
+  }
+  bool on() const { return t != nullptr; }
+  void add(float* base, size_t n) {
+    if (!on() || base == nullptr || n == 0) return;
+    if (t->count >= NR_FIX_RANGES || used + n > g_det_elems.load()) {
+      nr_set_error("deterministic mode: the registered scratch holds %zu elements, this call needs more than %zu", g_det_elems.load(), used + n);
+      rc = NR_ERR_ARG;
+      return;
+    }
+    t->base[t->count] = base; t->fix[t->count] = g_det_ws.load() + used; t->n[t->count] = n;
+    t->count++;
+    used += n;
+  }
+  int begin(bool in_gemm, bool in_pool) {
+    if (!on() || rc) return rc;
+    gemm = in_gemm; pool = in_pool; begun = true;
+    if (gemm && (rc = nr_fix_set_gemm(t, s))) return rc;
+    if (pool && (rc = nr_fix_set_pool(t, s))) return rc;
+    return NR_OK;
+  }
+  int end() {
+    if (!begun) return NR_OK;
+    begun = false;
+    int r = nr_fix_flush(t, s);
+    NrFixTable* z = &g_fix_ring[g_fix_pos];
+    g_fix_pos = (g_fix_pos + 1) & 63;
+    memset(z, 0, sizeof(*z));
+    if (gemm) { const int r2 = nr_fix_set_gemm(z, s); if (!r) r = r2; }
+    if (pool) { const int r2 = nr_fix_set_pool(z, s); if (!r) r = r2; }
+    return r;
+  }
+  ~DetScope() { (void)end(); }
+};
+}  // namespace
+
+namespace {
+thread_local DetScope* g_det_open[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+}
+int nr_det_open(hipStream_t s, float* base0, size_t n0, float* base1, size_t n1, bool gemm, bool pool, int* rc) {
+  *rc = NR_OK;
+  if (g_det_ws.load() == nullptr) return 0;
+  for (int h = 0; h < 8; ++h)
+    if (g_det_open[h] == nullptr) {
+      DetScope* d = new DetScope(s);
+      d->add(base0, n0);
+      d->add(base1, n1);
+      *rc = d->begin(gemm, pool);
+      if (*rc) { delete d; return 0; }
+      g_det_open[h] = d;
+      return h + 1;
+    }
+  nr_set_error("deterministic mode: too many nested scopes");
+  *rc = NR_ERR_ARG;
+  return 0;
+}
+int nr_det_close(int handle) {
+  if (handle <= 0 || handle > 8 || g_det_open[handle - 1] == nullptr) return NR_OK;
+  DetScope* d = g_det_open[handle - 1];
+  g_det_open[handle - 1] = nullptr;
+  const int rc = d->end();
+  delete d;
+  return rc;
+}
+
 // ---- side stream: two independent GEMMs of one backward composite run concurrently -----------------------------
 // The weight-gradient GEMM (LDS/MFMA bound) and the input-gradient GEMM (bound by L2 atomics or output stores)
 // consume the same upstream gradient and do not depend on each other.  fork: the side stream waits for everything
@@ -289,6 +372,13 @@ int nr_last_error(char* buf, size_t n) {
 int nr_abi_sizes(size_t* out, int n) {
   NR_CHECK_ARG(out != nullptr && n >= 4, "abi_sizes: need room for 4 entries");
   out[0] = sizeof(nr_mhsa_desc); out[1] = sizeof(nr_conv_desc); out[2] = sizeof(nr_pool_desc); out[3] = sizeof(nr_linear_desc);
+  return NR_OK;
+}
+
+int nr_set_deterministic(void* scratch, size_t bytes) {
+  NR_CHECK_ARG(scratch == nullptr || (bytes >= 8 && (((uintptr_t)scratch) & 7) == 0), "set_deterministic: scratch must be 8-byte aligned and non-empty");
+  g_det_elems.store(scratch ? bytes / 8 : 0);
+  g_det_ws.store(reinterpret_cast<long long*>(scratch));
   return NR_OK;
 }
 
@@ -555,7 +645,15 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
     Xs = dense_rows(d->x_rows, d->ld_rows, d->d_model);
   }
   const bool want_dx = dx != nullptr || dtable != nullptr;
-  const bool fork = want_dx && side_enabled() && M >= 65536;
+  DetScope det(s);
+  if (det.on()) {
+    NR_CHECK_ARG(dtable == nullptr || d->table_rows > 0, "mhsa_bwd: deterministic mode needs table_rows in the descriptor");
+    det.add(dw_qkv, (size_t)3 * N * d->d_model);
+    det.add(db_qkv, (size_t)3 * N);
+    if (dtable != nullptr) det.add(dtable, (size_t)d->table_rows * d->d_model);
+    if ((rc = det.begin(true, false))) return rc;
+  }
+  const bool fork = want_dx && side_enabled() && M >= 65536 && !det.on();
   hipStream_t s2 = s;
   if (fork && (rc = side_fork(s, &s2))) return rc;
   if (slab_ws != nullptr) {
@@ -592,7 +690,8 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
     const int rj = side_join(s);
     if (rc == NR_OK) rc = rj;
   }
-  return rc;
+  const int rd = det.end();
+  return rc ? rc : rd;
 }
 
 // ---------------------------------------------------------------------------------------- Conv1d k=3
@@ -643,6 +742,10 @@ int nr_conv1d_k3_bwd(const nr_conv_desc* d, const void* dy, float* dw_pack, floa
   NR_CHECK_ARG(d->bwd_ws == nullptr || d->bwd_ws_bytes >= conv_ws_elems(d->n, d->T) * sizeof(int32_t),
                "conv1d_bwd: bwd_ws holds %zu bytes, nr_conv_workspace_bytes() asks for %zu", d->bwd_ws_bytes,
                conv_ws_elems(d->n, d->T) * sizeof(int32_t));
+  DetScope det((hipStream_t)stream);                 // flushes when the function returns
+  det.add(dw_pack, (size_t)d->N * 3 * d->Dp);
+  det.add(db, (size_t)d->N);
+  if ((rc = det.begin(true, false))) return rc;
   if (d->x_rows != nullptr) {   // the rows the forward stored
     NR_CHECK_ARG(d->ld_rows >= 3 * d->Dp, "conv1d_bwd: ld_rows=%d must cover %d", d->ld_rows, 3 * d->Dp);
     A = dense_rows(d->x_rows, d->ld_rows, 3 * d->Dp);
@@ -706,6 +809,12 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
                pool_ws_elems(d->n, d->L, d->q) * sizeof(float));
   hipStream_t s = (hipStream_t)stream;
   const int M = d->n * d->L;
+  DetScope det(s);                                   // dw1 / db1 come from the GEMM kernels, dw2 / db2 from the column sums
+  det.add(dw1, (size_t)d->q * d->N);
+  det.add(db1, (size_t)d->q);
+  det.add(dw2, (size_t)d->q);
+  det.add(db2, 1);
+  if ((rc = det.begin(true, true))) return rc;
   // A sequence whose pooled gradient g is exactly zero (a history slot the user encoder masks out) has dA = <g, x> = 0,
   // so ds = 0 and its dpre rows are exact zeros: the core kernel only writes those zeros for it, and the att_fc1 weight
   // gradient contracts only the 32-row slabs that touch a sequence with g != 0.  The int scratch (n flags, count, M/32
@@ -721,7 +830,7 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
   if ((rc = nr_launch_pool_core_bwd(d->dtype, d->x, e, d->w2, alpha, g, ld_g, dpre, partial, dw2, db2, d->n, d->L, d->N, d->q, s, zero_flags)))
     return rc;
   RowSrc X = dense_rows(d->x, d->N, d->N);
-  const bool fork = dx != nullptr && side_enabled() && M >= 65536;
+  const bool fork = dx != nullptr && side_enabled() && M >= 65536 && !det.on();
   hipStream_t s2 = s;
   if (fork && (rc = side_fork(s, &s2))) return rc;
   if (ws != nullptr) {
@@ -787,6 +896,14 @@ int nr_linear_bwd(const nr_linear_desc* d, const float* dout, int ld_dout, void*
   NR_DEVICE_GUARD(stream, dw);
   NR_CHECK_ARG(d->dout_ws_bytes >= nr_linear_workspace_bytes(d), "linear_bwd: dout_ws holds %zu bytes, nr_linear_workspace_bytes() asks for %zu",
                d->dout_ws_bytes, nr_linear_workspace_bytes(d));
+  DetScope det((hipStream_t)stream);
+  if (det.on()) {
+    NR_CHECK_ARG(dtable == nullptr || d->table_rows > 0, "linear_bwd: deterministic mode needs table_rows in the descriptor");
+    det.add(dw, (size_t)d->N * d->K);
+    det.add(db, (size_t)d->N);
+    if (dtable != nullptr) det.add(dtable, (size_t)d->table_rows * d->K);
+    if ((rc = det.begin(true, false))) return rc;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int ch = nr_chunk(d->dtype), Nc = round_up(d->N, ch), Kp = round_up(d->K, ch);
   if ((rc = nr_launch_cast_rows(d->dtype, dout, ld_dout, dout_ws, Nc, d->M, d->N, s))) return rc;

@@ -150,6 +150,47 @@ static inline DropCfg nr_make_drop(float p, uint32_t seed) {
   return d;
 }
 
+// ---- order-independent accumulation (deterministic mode, nr_set_deterministic) ---------------------------
+// Gradient outputs that several workgroups add into (dW / db / dtable / dpad) are accumulated with fp32 atomics: the
+// result depends on the arrival order in the last bits.  In deterministic mode every contribution is rounded to 2^-36
+// fixed point and added with a 64-bit INTEGER atomic into a shadow buffer -- integer addition is associative, so the sum
+// is the same whatever the order -- and a flush pass adds the shadow (converted back) onto the fp32 output and zeroes it.
+// The ranges of the outputs of the call in flight live in a per-translation-unit device table that the entry point sets
+// (stream ordered) before its kernels and clears after them; an empty table (the default) means plain fp32 atomics.
+#define NR_FIX_RANGES 4
+struct NrFixTable {
+  int count;
+  int pad;
+  const float* base[NR_FIX_RANGES];
+  long long* fix[NR_FIX_RANGES];
+  unsigned long long n[NR_FIX_RANGES];
+};
+#ifdef __HIPCC__
+static __device__ NrFixTable g_nr_fix;      // one copy per translation unit (no relocatable device code)
+// `det` = nr_fix_on(), read ONCE per kernel (a per-element table lookup in the default mode cost the scatter epilogue 30 %)
+__device__ __forceinline__ bool nr_fix_on() { return g_nr_fix.count != 0; }
+__device__ __forceinline__ void nr_accum(float* p, float x, bool det) {
+  if (det) {
+    const int cnt = g_nr_fix.count;
+    for (int i = 0; i < cnt; ++i) {
+      const unsigned long long idx = (unsigned long long)(p - g_nr_fix.base[i]);
+      if (p >= g_nr_fix.base[i] && idx < g_nr_fix.n[i]) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(g_nr_fix.fix[i] + idx), (unsigned long long)__float2ll_rn(x * 68719476736.0f));
+        return;
+      }
+    }
+  }
+  atomicAdd(p, x);
+}
+#endif
+int nr_fix_set_gemm(const NrFixTable* t, hipStream_t s);   // nr_gemm.hip's copy of the table
+int nr_fix_set_pool(const NrFixTable* t, hipStream_t s);   // nr_pool.hip's copy
+int nr_fix_flush(const NrFixTable* t, hipStream_t s);      // out[i] += fix[i] * 2^-36 ; fix[i] = 0   for every range
+// One accumulation scope of an entry point outside nr_api.hip (which has its own RAII form): returns 0 when the mode is
+// off; otherwise registers up to two outputs, sets the tables, and nr_det_close flushes and clears them.
+int nr_det_open(hipStream_t s, float* base0, size_t n0, float* base1, size_t n1, bool gemm, bool pool, int* rc);
+int nr_det_close(int handle);
+
 // ---- small device helpers ----------------------------------------------------------------
 template <typename T> struct EltTraits;
 template <> struct EltTraits<float> { static constexpr int CH = 4; static constexpr int DT = NR_F32; };

@@ -231,11 +231,12 @@ __device__ __forceinline__ void emit4(const EpiArgs& ep, int m, int n, int N, f3
         for (int e = 0; e < 4; ++e) kb |= nr_keep(ep.drop.key, eidx + e, ep.drop.thresh) ? (1u << e) : 0u;
       }
     }
+    const bool det = nr_fix_on();
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (n + e >= ep.Dtrue) break;
       const float x = ((kb >> e) & 1u) ? v[e] * ep.drop.scale : 0.f;
-      if (x != 0.f) atomicAdd(dst + e, x);
+      if (x != 0.f) nr_accum(dst + e, x, det);
     }
     return;
   }
@@ -438,6 +439,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_kernel(const T* __restrict__ dC,
                                                        int tilesK, int rows_per_split) {
   using TL = TileCfg<T>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bool det = nr_fix_on();          // deterministic mode: fixed-point accumulation of the outputs (nr_common.h)
   T* sA = reinterpret_cast<T*>(smem);
   T* sB = sA + 2 * BM * TL::SK;
   float* sC = reinterpret_cast<float*>(smem);
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_kernel(const T* __restrict__ dC,
       constexpr int G = IS_BF16 ? 16 : 8;
 #pragma unroll
       for (int g = 0; g < G; ++g) sacc += sRed[g * 128 + tid];
-      atomicAdd(db + n0 + tid, sacc);
+      nr_accum(db + n0 + tid, sacc, det);
     }
     __syncthreads();
   }
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn_kernel(const T* __restrict__ dC,
         float* dst = dW + (size_t)n * ldw + k;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (k + e < Kstore) atomicAdd(dst + e, v[e]);
+          if (k + e < Kstore) nr_accum(dst + e, v[e], det);
       }
     }
   }
@@ -621,6 +623,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn2_kernel(const bf16_t* __restrict
                                                         int N, int K, int Nstore, int Kstore, int tilesK, int ntile, int nsplit,
                                                         int rps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bool det = nr_fix_on();          // deterministic mode: fixed-point accumulation of the outputs (nr_common.h)
   bf16_t* sA = reinterpret_cast<bf16_t*>(smem);           // [2][32][128]
   bf16_t* sB = sA + 2 * TBM * TBN;                        // [2][32][160]
   float* sC = reinterpret_cast<float*>(smem);
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn2_kernel(const bf16_t* __restrict
       float sacc = 0.f;
 #pragma unroll
       for (int t2 = 0; t2 < 16; ++t2) sacc += sRed[t2 * 128 + tid];
-      atomicAdd(db + n0 + tid, sacc);
+      nr_accum(db + n0 + tid, sacc, det);
     }
     __syncthreads();
   }
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(NTHR) void gemm_tn2_kernel(const bf16_t* __restrict
     for (int u = tid; u < 64 * TBK; u += NTHR) {   // lanes on consecutive floats (whole lines per atomic instruction)
       const int row = u / TBK, c = u - row * TBK;
       const int n = n0 + half * 64 + row, k = k0 + c;
-      if (n < Nstore && k < Kstore) atomicAdd(dW + (size_t)n * ldw + k, sC[row * SCW + c]);
+      if (n < Nstore && k < Kstore) nr_accum(dW + (size_t)n * ldw + k, sC[row * SCW + c], det);
     }
   }
 }
@@ -962,6 +965,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
   constexpr int SCW = WBN + 4;
   constexpr int AB = DBM * 64;                   // byte offset of the B tile inside a stage
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bool det = nr_fix_on();          // deterministic mode: fixed-point accumulation of the outputs (nr_common.h)
   float* sC = reinterpret_cast<float*>(smem);
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -1296,7 +1300,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
         for (int c = lane; c < N; c += 64) {
           float x = sC[rr * SCW + c];
           if (ep.drop.thresh) x = nr_keep(ep.drop.key, e0 + c, ep.drop.thresh) ? x * ep.drop.scale : 0.f;
-          if (x != 0.f && nbase + c < ep.Dtrue) atomicAdd(dst + c, x);
+          if (x != 0.f && nbase + c < ep.Dtrue) nr_accum(dst + c, x, det);
         }
       }
     } else {
@@ -1398,6 +1402,7 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
                 STAGE = G::STAGE;
   constexpr int PB = NP / NW, PX = NP % NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bool det = nr_fix_on();          // deterministic mode: fixed-point accumulation of the outputs (nr_common.h)
   float* sC = reinterpret_cast<float*>(smem);
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -1517,7 +1522,7 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int ti = 4 * (lane >> 4) + e, n = n0 + wm * 16 * NI + ti * 16 + (lane & 15);
-      if (ti < NI && n < Nstore) atomicAdd(db + n, accdb[e]);
+      if (ti < NI && n < Nstore) nr_accum(db + n, accdb[e], det);
     }
   }
 #pragma unroll
@@ -1539,7 +1544,7 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
     for (int u = tid; u < 64 * TBK; u += NT) {
       const int row = u / TBK, c = u - row * TBK;
       const int n = n0 + pass * 64 + row, k = k0 + c;
-      if (n < Nstore && k < Kstore) atomicAdd(dW + (size_t)n * ldw + k, sC[row * SCW + c]);
+      if (n < Nstore && k < Kstore) nr_accum(dW + (size_t)n * ldw + k, sC[row * SCW + c], det);
     }
   }
 }
@@ -1789,6 +1794,11 @@ __global__ void row0_flag_kernel(const bf16_t* __restrict__ row0, int cols, int3
 }
 }  // namespace
 
+int nr_fix_set_gemm(const NrFixTable* t, hipStream_t s) {
+  NR_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nr_fix), t, sizeof(NrFixTable), 0, hipMemcpyHostToDevice, s));
+  return NR_OK;
+}
+
 int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* ws, hipStream_t stream) {
   NR_CHECK_ARG(ids != nullptr && ws != nullptr && M > 0 && ids_stride >= 1, "compact_rows: bad arguments");
   NR_CHECK_HIP(hipMemsetAsync(ws, 0, 4 * sizeof(int32_t), stream));
@@ -1889,27 +1899,35 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
 
 namespace {
 // 32-row slabs of a [n*L, *] tensor that touch at least one sequence flagged in title_nz, in order; ws[0] = their number
-__global__ __launch_bounds__(256) void live_slabs_kernel(const int32_t* __restrict__ title_nz, int n, int L, int nslab,
-                                                         int32_t* __restrict__ count, int32_t* __restrict__ list) {
-  __shared__ int wave_cnt[4];
-  __shared__ int base;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int s = blockIdx.x * 256 + tid;
-  bool live = false;
-  if (s < nslab) {
+// ORDERED compaction by one workgroup (nslab is ~26 000 at the bench shape): every thread owns a contiguous run of slabs,
+// counts its live ones, the block scans the counts, and the runs are written back to back -- the list is ascending, so the
+// order in which a split of the weight-gradient GEMM contracts its slabs (and with it every fp32 rounding) is the same
+// from run to run.
+__global__ __launch_bounds__(1024) void live_slabs_kernel(const int32_t* __restrict__ title_nz, int n, int L, int nslab,
+                                                          int32_t* __restrict__ count, int32_t* __restrict__ list) {
+  __shared__ int sCnt[1024];
+  const int tid = threadIdx.x;
+  const int per = (nslab + 1023) / 1024, s0 = tid * per, s1 = min(nslab, s0 + per);
+  auto live = [&](int s) {
     const int t0 = (32 * s) / L, t1 = min(n - 1, (32 * s + 31) / L);
-    for (int t = t0; t <= t1; ++t) live |= title_nz[t] != 0;
-  }
-  const uint64_t bal = __ballot(live);
-  if (lane == 0) wave_cnt[wid] = __popcll(bal);
+    bool lv = false;
+    for (int t = t0; t <= t1; ++t) lv |= title_nz[t] != 0;
+    return lv;
+  };
+  int c = 0;
+  for (int s = s0; s < s1; ++s) c += live(s) ? 1 : 0;
+  sCnt[tid] = c;
   __syncthreads();
-  if (tid == 0) base = atomicAdd(count, wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]);
-  __syncthreads();
-  if (live) {
-    int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wid; ++w) pos += wave_cnt[w];
-    list[pos] = s;
+  for (int o = 1; o < 1024; o <<= 1) {                    // inclusive Hillis-Steele scan
+    const int v = tid >= o ? sCnt[tid - o] : 0;
+    __syncthreads();
+    sCnt[tid] += v;
+    __syncthreads();
   }
+  int pos = sCnt[tid] - c;
+  for (int s = s0; s < s1; ++s)
+    if (live(s)) list[pos++] = s;
+  if (tid == 1023) *count = sCnt[1023];
 }
 }  // namespace
 
@@ -2044,12 +2062,12 @@ int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, in
 }
 
 // ws: int32 [n + 4 + M/32]: ws[0..n) = title_nz (nr_launch_title_flags), ws[n] = slab count, ws[n+4 ..] slab list.
-// The order of the list follows workgroup arrival (arbitrary): the contraction does not care.
+// The list is ascending (see live_slabs_kernel).
 int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream) {
   const int M = n * L, nslab = M / 32;
   NR_CHECK_ARG(ws != nullptr && M % 32 == 0, "live_slabs: bad arguments");
   NR_CHECK_HIP(hipMemsetAsync(ws + n, 0, 4 * sizeof(int32_t), stream));
-  hipLaunchKernelGGL(live_slabs_kernel, dim3((nslab + 255) / 256), dim3(256), 0, stream, ws, n, L, nslab, ws + n, ws + n + 4);
+  hipLaunchKernelGGL(live_slabs_kernel, dim3(1), dim3(1024), 0, stream, ws, n, L, nslab, ws + n, ws + n + 4);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     for (int r = blockIdx.y * 4 + ry; r < rows; r += 4 * gridDim.y) s += in[(size_t)r * ld + c];
   red[ry][cx] = s;
   __syncthreads();
-  if (ry == 0 && c < cols) atomicAdd(out + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+  if (ry == 0 && c < cols) nr_accum(out + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx], nr_fix_on());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void blend_bwd_kernel(const T* __restrict__ do
       dx[(size_t)r * N + c] = d * m;
       acc = fmaf(1.f - m, d, acc);
     }
-    if (mask && dpad) atomicAdd(dpad + c, acc);
+    if (mask && dpad) nr_accum(dpad + c, acc, nr_fix_on());
   }
 }
 
@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
   if (r >= n_ids) return;
   const int id = ids[(size_t)r * ids_stride];
   if (id == 0) return;  // padding_idx
-  for (int c = lane; c < cols; c += 64) atomicAdd(dtable + (size_t)id * ld_dtable + c, dout[(size_t)r * ld_dout + c]);
+  const bool det = nr_fix_on();
+  for (int c = lane; c < cols; c += 64) nr_accum(dtable + (size_t)id * ld_dtable + c, dout[(size_t)r * ld_dout + c], det);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -505,6 +506,32 @@ int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float
   return NR_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void fix_flush_kernel(float* __restrict__ out, long long* __restrict__ fix, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const long long v = fix[i];
+    if (v != 0) {
+      out[i] += (float)((double)v * (1.0 / 68719476736.0));
+      fix[i] = 0;
+    }
+  }
+}
+}  // namespace
+int nr_fix_set_pool(const NrFixTable* t, hipStream_t s) {
+  NR_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nr_fix), t, sizeof(NrFixTable), 0, hipMemcpyHostToDevice, s));
+  return NR_OK;
+}
+int nr_fix_flush(const NrFixTable* t, hipStream_t s) {
+  for (int i = 0; i < t->count; ++i) {
+    const size_t n = (size_t)t->n[i];
+    if (n == 0) continue;
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(fix_flush_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, s, const_cast<float*>(t->base[i]), t->fix[i], n);
+  }
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
 int nr_launch_cast_rows(int dtype, const float* src, int ld_src, void* dst, int ld_dst, int rows, int cols, hipStream_t s) {
   const size_t total = (size_t)rows * ld_dst;
   if (dtype == NR_BF16)
@@ -601,13 +628,16 @@ int nr_pad_blend_bwd(const void* dout, const float* mask, float* dx, float* dpad
   NR_DEVICE_GUARD(stream, dx);
   const int rows = n * L, rpb = 32;
   hipStream_t s = (hipStream_t)stream;
+  int det_rc = NR_OK;
+  const int det = (mask != nullptr && dpad != nullptr) ? nr_det_open(s, dpad, (size_t)N, nullptr, 0, false, true, &det_rc) : 0;
+  if (det_rc) return det_rc;
   NrProfScope ps(s, "pad_blend_bwd[n=%d,L=%d,N=%d]", n, L, N);
   if (dtype == NR_BF16)
     hipLaunchKernelGGL(blend_bwd_kernel<bf16_t>, dim3((rows + rpb - 1) / rpb), dim3(256), 0, s, (const bf16_t*)dout, mask, dx, dpad, rows, N, rpb);
   else
     hipLaunchKernelGGL(blend_bwd_kernel<float>, dim3((rows + rpb - 1) / rpb), dim3(256), 0, s, (const float*)dout, mask, dx, dpad, rows, N, rpb);
   NR_CHECK_LAUNCH();
-  return NR_OK;
+  return nr_det_close(det);
 }
 
 int nr_score_ce_fwd(const float* cand, int ld_cand, const float* user, const int64_t* label, float* score, float* loss,

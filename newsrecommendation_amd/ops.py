@@ -127,6 +127,25 @@ def _take_flags(seq, dy, n):
     return 0, None
 
 
+# Deterministic mode (nr_set_deterministic): gradients that several workgroups add into are accumulated in fixed point with
+# integer atomics, so they are bit-reproducible from run to run.  Costs a zeroed scratch of 8 bytes per accumulated element
+# of the largest backward call and a flush pass per call; off by default.
+_det_scratch = None
+
+
+def set_deterministic(on: bool, elements: int = 1 << 24, device=None) -> None:
+    """on: register a zero-filled scratch of `elements` int64 (default 16 M = 128 MB: NRMS with a 30 000-row trainable
+    word table needs 3*400*301 + 30 000*300 = 9.4 M) with libnrhip; off: plain fp32 atomics again."""
+    global _det_scratch
+    if on:
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        _det_scratch = torch.zeros(int(elements), dtype=torch.int64, device=dev)
+        check(_lib.lib().nr_set_deterministic(ptr(_det_scratch), _det_scratch.numel() * 8), "nr_set_deterministic")
+    else:
+        check(_lib.lib().nr_set_deterministic(None, 0), "nr_set_deterministic")
+        _det_scratch = None
+
+
 def grad_target(p):
     """The preallocated gradient view of a parameter that lives in a flat bucket (parallel.FlatBucket sets
     `_nr_grad`), or None.  Backward passes ACCUMULATE into such a view directly -- the kernels add into their dW / db /
@@ -324,7 +343,7 @@ class MHSAFunction(Function):
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
                           x_rows=ptr(x_rows), ld_rows=x_rows.shape[1] if x_rows is not None else 0,
-                          seq_nz=seq_nz, row_ws_ready=int(ws_ready))
+                          table_rows=cfg["table_shape"][0] if gather else 0, seq_nz=seq_nz, row_ws_ready=int(ws_ready))
         if need_x:
             w_t = pack(wcat, code, transpose=True)                     # [d_model, 3N]
             if gather:
@@ -716,7 +735,7 @@ class GatherLinearFunction(Function):
         w_t = pack(w, code, transpose=True, ld=Nc) if need_t else None               # [K, Nc]
         d = _lib.LinearDesc(M=M, K=K, N=N, dtype=code, src_kind=NR_SRC_GATHER, x=ptr(emb_p), ldx=emb_p.shape[1],
                             ids=ctx.ids.data_ptr(), ids_stride=stride, w=ptr(w_p), ldw=w_p.shape[1], bias=ptr(b_c),
-                            w_t=ptr(w_t), ldwt=Nc if need_t else 0)
+                            w_t=ptr(w_t), ldwt=Nc if need_t else 0, table_rows=emb_shape[0])
         ws = _ws(_lib.lib().nr_linear_workspace_bytes(C.byref(d)), dev)
         d.dout_ws_bytes = ws.numel() * 4
         check(_lib.lib().nr_linear_bwd(C.byref(d), ptr(dout), N, ptr(ws), ptr(dw), ptr(db), ptr(dtable), _stream()), "nr_linear_bwd")

@@ -116,6 +116,8 @@ def train(rank, args, news_index, news_combined, embedding_matrix, category_dict
     if getattr(args, "load_ckpt_name", None):
         model.load_state_dict(load_checkpoint(os.path.join(args.model_dir, args.load_ckpt_name))["model_state_dict"])
     model = model.to(device)                                   # before the optimizer: its state follows the parameters' device
+    if getattr(args, "deterministic", False) and on_gpu:       # bit-reproducible gradients (fixed-point integer atomics)
+        ops.set_deterministic(True, elements=sum(p.numel() for p in model.parameters()) + (1 << 20), device=device)
     mode = getattr(args, "dp_mode", None) or ("flat" if on_gpu else "ddp")
     net, bucket, optimizer = model, None, None
     if mode == "flat":

@@ -215,3 +215,43 @@ def test_flat_bucket_over_rccl_single_rank():
         assert float((diff > 1.5e-3).float().mean()) < 1e-3
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model_name", ["NRMS", "NAML"])
+def test_deterministic_mode_gives_bit_identical_gradients(model_name):
+    """ops.set_deterministic(True): every gradient several workgroups add into (dW, db, the word-table gradient, pad_doc) is
+    accumulated in 2^-36 fixed point with integer atomics -- two runs of the same training step (dropout on) must agree
+    BIT FOR BIT at the production-scale shapes, and with the default fp32-atomic run up to the order of its additions."""
+    def run():
+        if model_name == "NRMS":
+            cfg, sd, m, batch = _nrms_case("bf16", 80)
+        else:
+            from newsrecommendation_amd.model import NAML
+            cfg = O.default_cfg(use_category=True, use_subcategory=True, freeze_embedding=True)
+            g = torch.Generator().manual_seed(81)
+            table = torch.randn(2501, cfg.num_words_title * cfg.word_embedding_dim, generator=g) * 0.4
+            table[0] = 0
+            sd = O.init_state_dict("NAML", cfg, table, seed=82, n_cat=17, n_sub=264)
+            m = NAML.Model(SimpleNamespace(**vars(cfg), compute_dtype="bf16"), table.numpy(), 17, 264)
+            m.load_state_dict(sd, strict=True)
+            m = m.cuda()
+            batch = bench.synth_batches_naml(cfg, B, 2500, 1, 83, "cpu")[0]
+        m.train()
+        torch.manual_seed(2024)
+        loss, score = m(*(x.cuda() for x in batch))
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    plain_loss, plain = run()
+    ops.set_deterministic(True)
+    try:
+        l1, g1 = run()
+        l2, g2 = run()
+    finally:
+        ops.set_deterministic(False)
+    assert torch.equal(l1, l2) and torch.equal(l1, plain_loss)
+    assert g1.keys() == g2.keys() == plain.keys() and len(g1) >= 10
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), f"{k}: not bit-reproducible (max diff {float((g1[k] - g2[k]).abs().max()):.3e})"
+        assert float((g1[k] - plain[k]).abs().max()) <= 1e-5 * float(plain[k].abs().max()) + 1e-8, k
