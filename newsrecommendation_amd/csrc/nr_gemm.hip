@@ -1340,7 +1340,9 @@ int launch_nt_dma_p(const RowSrc& A, const void* B, int ldb, int M, int N, int K
   const bool wm2_all = nr_opt(NR_OPT_DMA_WM2_ALL) != 0;
   // short contractions (K <= 224: at most 7 k-steps) are all pipeline fill and epilogue: two workgroups per CU overlap
   // them even with two column chunks (pooling dX, N = 400, K = 200: 0.445 -> 0.372 ms)
-  if (fits2 && (N <= NT16 * 16 || K <= 224 || wm2_all)) return launch_nt_dma_w<EPI, NT16, PK, 2>(A, B, ldb, M, N, K, ep, stream);
+  // ... and up to two column chunks the second read of A is cheaper than the idle fill / epilogue phases of a lone
+  // workgroup (NAML conv, N = 400, K = 960: 0.738 -> 0.694 ms); six chunks (QKV projection) still lose (0.51 -> 0.57)
+  if (fits2 && (N <= 2 * NT16 * 16 || K <= 224 || wm2_all)) return launch_nt_dma_w<EPI, NT16, PK, 2>(A, B, ldb, M, N, K, ep, stream);
   return launch_nt_dma_w<EPI, NT16, PK, 4>(A, B, ldb, M, N, K, ep, stream);
 }
 
