@@ -239,7 +239,7 @@ def roofline_of(prof, dtype, struct):
     return out
 
 
-def step_roofline(model_name, dtype, batch, ms_per_step):
+def step_roofline(model_name, dtype, batch, ms_per_step, plain=True):
     """Whole training step against the binding bound of SURVEY §8(d): algorithmic FLOPs (3 x forward) / time / dense MFMA
     peak, and the HBM bytes a step moves (sum over all dispatches of the committed PMC passes) against the fused minimum
     (forward minimum x 3: activations are read again and their gradients written in the backward)."""
@@ -251,7 +251,7 @@ def step_roofline(model_name, dtype, batch, ms_per_step):
     fused_min = 3.0 * FUSED_MIN_BYTES_PER_IMP_FWD[dtype] * batch
     out["fused_min_bytes"] = int(fused_min)
     tot = pm.get("step_total") if pm else None
-    if tot and tot.get("model") == model_name and tot.get("dtype") == dtype and tot.get("batch") == batch:
+    if plain and tot and tot.get("model") == model_name and tot.get("dtype") == dtype and tot.get("batch") == batch:
         out["hbm_bytes_per_step_pmc"] = int(tot["bytes_per_step"])
         out["wasted_traffic_ratio"] = round(tot["bytes_per_step"] / fused_min, 2)
         out["hbm_frac_of_peak_at_measured_time"] = round(tot["bytes_per_step"] / (ms_per_step / 1e3) / 1e9 / PEAK_HBM, 4)
@@ -603,7 +603,9 @@ def main():
                           "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "batch_structure": struct}}
         out["roofline"] = roofline_of(prof, a.dtype, struct)
         if out["roofline"] is not None:
-            out["roofline"]["step"] = step_roofline(a.model, a.dtype, a.batch, ms_step)
+            # the committed PMC passes profile the default (sparse, resident, non-deterministic) workload only
+            out["roofline"]["step"] = step_roofline(a.model, a.dtype, a.batch, ms_step,
+                                                    plain=not (a.dense_batch or a.deterministic or a.compact_history))
         if prof:
             tot = sum(ms for _, ms in prof.values())
             top = sorted(prof.items(), key=lambda kv: -kv[1][1])[:(None if a.all_kernels else 12)]

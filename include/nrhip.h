@@ -94,6 +94,10 @@ int nr_embed_gather_fwd(const void* table, int ld_table, int dtype, const int32_
                         int ids_stride, int cols, float* out, int ld_out, nr_stream_t stream);
 int nr_embed_gather_bwd(const float* dout, int ld_dout, const int32_t* ids, int n_ids, int ids_stride,
                         int cols, float* dtable, int ld_dtable, nr_stream_t stream);
+/* Eval-time gather of news vectors straight into the compute dtype (src/dataset.py:68 `news_scoring[click_docs]` + the
+ * cast the user encoder would do next): out[m, 0:cols] = (out_dtype) table[ids[m], 0:cols], table fp32.              */
+int nr_gather_cast_fwd(const float* table, int ld_table, const int32_t* ids, int n_ids, int cols, void* out, int ld_out,
+                       int out_dtype, nr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * K3 (+K1,K2 fused)  multi-head self-attention — MultiHeadSelfAttention.forward +

@@ -80,6 +80,7 @@ SIGNATURES = {
     "nr_unpack_conv_dw": [_vp, _i, _i, _i, _vp, _i, _vp],
     "nr_embed_gather_fwd": [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp],
     "nr_embed_gather_bwd": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp],
+    "nr_gather_cast_fwd": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     "nr_mhsa_fwd_fused": [C.POINTER(MhsaDesc)],
     "nr_mhsa_fwd": [C.POINTER(MhsaDesc), _vp, _vp, _vp],
     "nr_mhsa_bwd": [C.POINTER(MhsaDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],

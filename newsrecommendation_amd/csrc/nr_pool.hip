@@ -596,6 +596,41 @@ int nr_embed_gather_fwd(const void* table, int ld_table, int dtype, const int32_
   return NR_OK;
 }
 
+namespace {
+// fp32 table rows -> bf16 rows (gather + cast in one pass): one wave per row, 8 elements (32 B in, 16 B out) per lane step
+__global__ __launch_bounds__(256) void gather_cast_kernel(const float* __restrict__ table, int ld_table, const int32_t* __restrict__ ids,
+                                                          int n_ids, int cols, bf16_t* __restrict__ out, int ld_out) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= n_ids) return;
+  const float* src = table + (size_t)ids[r] * ld_table;
+  bf16_t* dst = out + (size_t)r * ld_out;
+  const bool vec = (cols % 8 == 0) && (ld_table % 4 == 0) && (ld_out % 8 == 0) && ((((uintptr_t)table) | ((uintptr_t)out)) & 15) == 0;
+  if (vec) {
+    for (int c = lane * 8; c < cols; c += 64 * 8) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + c), b = *reinterpret_cast<const f32x4*>(src + c + 4);
+      const bf16x8 o = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+      *reinterpret_cast<bf16x8*>(dst + c) = o;
+    }
+  } else {
+    for (int c = lane; c < cols; c += 64) dst[c] = (bf16_t)src[c];
+  }
+}
+}  // namespace
+
+int nr_gather_cast_fwd(const float* table, int ld_table, const int32_t* ids, int n_ids, int cols, void* out, int ld_out, int out_dtype,
+                       nr_stream_t stream) {
+  NR_CHECK_ARG(table && ids && out, "gather_cast_fwd: null pointer");
+  NR_CHECK_ARG(out_dtype == NR_F32 || out_dtype == NR_BF16, "gather_cast_fwd: bad dtype %d", out_dtype);
+  if (out_dtype == NR_F32) return nr_embed_gather_fwd(table, ld_table, NR_F32, ids, n_ids, 1, cols, (float*)out, ld_out, stream);
+  NR_DEVICE_GUARD(stream, out);
+  if (n_ids == 0) return NR_OK;
+  NR_CHECK_ARG(n_ids > 0 && cols > 0 && ld_out >= cols && ld_table >= cols, "gather_cast_fwd: bad sizes");
+  NrProfScope ps((hipStream_t)stream, "gather_cast[n=%d,cols=%d]", n_ids, cols);
+  hipLaunchKernelGGL(gather_cast_kernel, dim3((n_ids + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ld_table, ids, n_ids, cols, (bf16_t*)out, ld_out);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
 int nr_embed_gather_bwd(const float* dout, int ld_dout, const int32_t* ids, int n_ids, int ids_stride, int cols,
                         float* dtable, int ld_dtable, nr_stream_t stream) {
   NR_CHECK_ARG(dout && ids && dtable, "embed_gather_bwd: null pointer");

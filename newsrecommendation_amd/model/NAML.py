@@ -72,7 +72,8 @@ class UserEncoder(nn.Module):
     def forward(self, news_vecs, log_mask=None):
         code = ops.dtype_code(_cd(self.args))
         if self.args.user_log_mask:
-            return self.attn(ops.to_compute(news_vecs.float(), code), log_mask)
+            x = news_vecs if news_vecs.dtype == ops.torch_dtype(code) else ops.to_compute(news_vecs.float(), code)
+            return self.attn(x, log_mask)
         return self.attn(ops.pad_blend(news_vecs, log_mask, self.pad_doc, code))
 
 

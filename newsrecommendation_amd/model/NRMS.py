@@ -50,7 +50,7 @@ class UserEncoder(nn.Module):
         """news_vecs: [B, H, news_dim]; log_mask: [B, H] -> [B, news_dim] fp32."""
         code = ops.dtype_code(_cd(self.args))
         if self.args.user_log_mask:
-            x = ops.to_compute(news_vecs.float(), code)
+            x = news_vecs if news_vecs.dtype == ops.torch_dtype(code) else ops.to_compute(news_vecs.float(), code)
             y = self.multi_head_self_attn(x, mask=log_mask)
             return self.attn(y, log_mask)
         x = ops.pad_blend(news_vecs, log_mask, self.pad_doc, code)

@@ -751,17 +751,18 @@ def gather_linear(emb, w, b, ids, code: int):
 
 
 # ------------------------------------------------------------------------------------------ plain row gather (eval path)
-def embed_gather(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
-    """out[i] = table[ids[i]] (fp32), no gradient: the eval-time news-vector lookup of src/dataset.py:68,72."""
+def embed_gather(table: torch.Tensor, ids: torch.Tensor, code: int = NR_F32) -> torch.Tensor:
+    """out[i] = table[ids[i]], no gradient: the eval-time news-vector lookup of src/dataset.py:68,72.  `code`: dtype of the
+    result (fp32, or bf16 = gather + the cast the user encoder would do next, in one pass)."""
     _need_gpu(table, ids)
     table = table.detach().float().contiguous()
     ids = ids.to(torch.int32).contiguous()
     if CHECK_INDICES:
         check_ids(ids, table.shape[0], "news index")
     cols = table.shape[1]
-    out = torch.empty(*ids.shape, cols, dtype=torch.float32, device=table.device)
-    check(_lib.lib().nr_embed_gather_fwd(ptr(table), cols, NR_F32, ptr(ids), ids.numel(), 1, cols, ptr(out), cols, _stream()),
-          "nr_embed_gather_fwd")
+    out = torch.empty(*ids.shape, cols, dtype=torch_dtype(code), device=table.device)
+    check(_lib.lib().nr_gather_cast_fwd(ptr(table), cols, ptr(ids), ids.numel(), cols, ptr(out), cols, code, _stream()),
+          "nr_gather_cast_fwd")
     return out
 
 

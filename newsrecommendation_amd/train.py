@@ -216,9 +216,13 @@ def score_shard(model, news_vecs, shard: IndexedTestShard, batch_size, device):
     hist = torch.as_tensor(shard.hist, device=device)
     mask = torch.as_tensor(shard.mask, device=device)
     user = torch.empty(n, news_vecs.shape[1], dtype=torch.float32, device=device)
+    # masked user encoder (src/demo.sh:26): the gather can hand over the compute dtype directly (gather + cast in one pass)
+    margs = getattr(model, "args", None)
+    code = ops.dtype_code(getattr(margs, "compute_dtype", "fp32")) if getattr(margs, "user_log_mask", False) else ops.NR_F32
+    batch_size = max(int(batch_size), 8192)                    # the user encoder is row-wise: bigger chunks, same vectors
     for a in range(0, n, batch_size):
         b = min(n, a + batch_size)
-        log_vecs = ops.embed_gather(news_vecs, hist[a:b])                             # [B, H, news_dim], device gather
+        log_vecs = ops.embed_gather(news_vecs, hist[a:b], code)                       # [B, H, news_dim], device gather
         user[a:b] = model.user_encoder(log_vecs, mask[a:b])                           # src/main.py:247
     offsets = torch.as_tensor(shard.offsets, device=device)
     counts = shard.offsets[1:] - shard.offsets[:-1]
