@@ -191,7 +191,9 @@ def price_kernel(label, avg_ms, struct, dtype):
         by = n * L * (N + q) * esz * (1 if "fwd" in name else 1) + n * L * q * esz * (0 if "fwd" in name else 1)
         return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}
     if name.startswith("rows_materialize"):
-        M, K = _dims(label, r"M=(\d+),K=(\d+)")
+        M, K = _dims(label, r"M(?:max)?=(\d+),K=(\d+)")
+        if name.endswith("_needed"):
+            M = M * struct.get("needed_tiles", 1.0)              # titles near a needed one (upper bound: tile granularity)
         by = M * K * esz
         return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}
     return None

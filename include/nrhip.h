@@ -208,9 +208,11 @@ typedef struct {
                          one (masked history slots have an exactly zero dy).  NULL: every row is contracted.          */
   size_t bwd_ws_bytes; /* size of bwd_ws in bytes, >= nr_conv_workspace_bytes(d) when bwd_ws != NULL (checked)              */
   const int32_t* seq_nz; /* nr_conv1d_k3_bwd only, optional [n]: 0 = dy of this title is exactly zero (see nr_pool_seq_flags)  */
-  const int32_t* seq_needed; /* nr_conv1d_k3_fwd only, optional [n]: 0 = the caller will not use this title's output (see nr_mhsa_desc):
-                         row tiles made of such titles only are not computed and their y rows stay UNWRITTEN -- the consumer
-                         (nr_additive_pool_fwd / _bwd with the same flags) never reads them                                    */
+  const int32_t* seq_needed; /* optional [n]: 0 = the caller will not use this title's output (see nr_mhsa_desc).  nr_conv1d_k3_fwd
+                         does not compute row tiles made of such titles only -- their y rows stay UNWRITTEN, the consumer
+                         (nr_additive_pool_fwd / _bwd with the same flags) never reads them -- and, on shapes whose backward
+                         contracts live slabs only, does not store the x_rows of titles far from every needed one;
+                         nr_conv1d_k3_bwd must then be given the same flags and bwd_ws                                         */
 } nr_conv_desc;
 size_t nr_conv_workspace_bytes(const nr_conv_desc* d);
 int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream);

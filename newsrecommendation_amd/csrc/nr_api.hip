@@ -302,6 +302,14 @@ static bool pool_has_flags(const nr_pool_desc* d) {
   return !nr_opt(NR_OPT_NO_SLABS) && d->dtype == NR_BF16 && M % 32 == 0 && d->L <= 32 && nr_gemm_tn_slabs_ok(d->q, d->N, M, d->q, d->N);
 }
 
+// Shapes whose conv backward contracts live 32-row slabs only (bf16, rows a multiple of 32, tn3-eligible): only then may the
+// forward leave the im2col rows of far-from-needed titles unwritten
+static bool conv_slab_shape(const nr_conv_desc* d) {
+  const int M = d->n * d->T;
+  return !nr_opt(NR_OPT_NO_SLABS) && d->dtype == NR_BF16 && d->x_rows != nullptr && M % 32 == 0 && d->T <= 32 && d->N % 8 == 0 &&
+         nr_gemm_tn_slabs_ok(d->N, d->ld_rows, M, d->N, 3 * d->Dp);
+}
+
 static int mhsa_check(const nr_mhsa_desc* d) {
   NR_CHECK_ARG(d != nullptr, "mhsa: null descriptor");
   NR_CHECK_ARG(dtype_ok(d->dtype), "mhsa: bad dtype %d", d->dtype);
@@ -726,7 +734,12 @@ int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream) {
   if (d->x_rows != nullptr) {
     // im2col rows (gather + dropout hashed once) -> dense operand for the LDS-DMA GEMM
     NR_CHECK_ARG(d->ld_rows >= K && d->ld_rows % nr_chunk(d->dtype) == 0, "conv1d_fwd: ld_rows=%d must cover %d", d->ld_rows, K);
-    if ((rc = nr_launch_rows_materialize(d->dtype, A, d->x_rows, d->ld_rows, M, K, s))) return rc;
+    // with "needed" flags only the titles near a needed one are materialised: a 256-row GEMM tile / a 32-row slab spans
+    // at most 256 / T + 2 titles
+    // (only on shapes whose backward reads x_rows through the live-slab list -- a dense contraction would read every row)
+    if ((rc = nr_launch_rows_materialize(d->dtype, A, d->x_rows, d->ld_rows, M, K, s, conv_slab_shape(d) ? d->seq_needed : nullptr,
+                                         256 / d->T + 2)))
+      return rc;
     A = dense_rows(d->x_rows, d->ld_rows, K);
   }
   return nr_launch_gemm_nt(d->dtype, A, d->w_pack, K, M, d->N, K, EPI_STORE, ep, s);
@@ -752,6 +765,9 @@ int nr_conv1d_k3_bwd(const nr_conv_desc* d, const void* dy, float* dw_pack, floa
     // titles with an exactly zero upstream gradient (masked history slots) add nothing to dW / db: live slabs only
     const bool no_slabs = nr_opt(NR_OPT_NO_SLABS) != 0;
     const int M = d->n * d->T;
+    // x_rows written under "needed" flags are complete only where a live slab can reach: the slab path is then mandatory
+    NR_CHECK_ARG(!(d->seq_needed != nullptr && conv_slab_shape(d)) || (d->bwd_ws != nullptr && (((uintptr_t)dy) & 15) == 0),
+                 "conv1d_bwd: x_rows were materialised under seq_needed: bwd_ws (and a 16-byte aligned dy) are required");
     if (!no_slabs && d->bwd_ws != nullptr && d->dtype == NR_BF16 && M % 32 == 0 && d->T <= 32 && d->N % 8 == 0 &&
         (((uintptr_t)dy) & 15) == 0 && nr_gemm_tn_slabs_ok(d->N, d->ld_rows, M, d->N, 3 * d->Dp)) {
       hipStream_t s = (hipStream_t)stream;

@@ -1693,6 +1693,35 @@ __global__ __launch_bounds__(256) void im2col3_materialize_kernel(RowSrc A, T* _
   }
 }
 
+// The same, one workgroup per title, for callers that say which titles anybody needs: a title farther than `margin` titles
+// from every needed one lies in no row tile the projection computes and in no 32-row slab the weight gradient contracts
+// (both cover at most margin titles), so its im2col rows are never read and are not written.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3_title_kernel(RowSrc A, T* __restrict__ out, int ldo, int M, const int32_t* __restrict__ needed,
+                                                            int n, int margin) {
+  constexpr int CH = 16 / (int)sizeof(T);
+  const int Dp = A.ld, cpr = Dp / CH, T_ = A.Tlen, blk = blockIdx.x;
+  __shared__ int near;
+  if (threadIdx.x == 0) near = 0;
+  __syncthreads();
+  for (int t = max(0, blk - margin) + (int)threadIdx.x; t <= min(n - 1, blk + margin); t += 256)
+    if (needed[t] != 0) near = 1;                        // benign race: every writer stores 1
+  __syncthreads();
+  if (!near) return;
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  for (int u = threadIdx.x; u < T_ * cpr; u += 256) {
+    const int t = u / cpr, d = (u - t * cpr) * CH, m = blk * T_ + t;
+    if (m >= M) break;
+    const uint4 v = load_rows_chunk<T, ROWS_IM2COL3>(A, m, Dp + d, M, 3 * Dp);
+    T* o = out + (size_t)m * ldo + d;
+    *reinterpret_cast<uint4*>(o + Dp) = v;
+    if (t + 1 < T_) *reinterpret_cast<uint4*>(o + ldo) = v;
+    else *reinterpret_cast<uint4*>(o + 2 * Dp) = zero;
+    if (t > 0) *reinterpret_cast<uint4*>(o - ldo + 2 * Dp) = v;
+    else *reinterpret_cast<uint4*>(o) = zero;
+  }
+}
+
 // Row compaction for the table-gradient GEMM: rows with token id 0 add nothing (padding_idx), and in a MIND-shaped
 // batch they are ~70 % of all rows (zero-padded title tails, empty history slots).  One pass, no host round trip:
 // 256 rows per workgroup, order kept inside a workgroup, workgroups append through one atomic counter.
@@ -1837,9 +1866,20 @@ int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_
   return NR_OK;
 }
 
-int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, int M, int K, hipStream_t stream) {
+int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, int M, int K, hipStream_t stream, const int32_t* needed,
+                               int margin) {
   const int ch = nr_chunk(dtype);
   NR_CHECK_ARG((A.kind == ROWS_GATHER || A.kind == ROWS_IM2COL3) && K % ch == 0 && ldo % ch == 0 && ldo >= K, "rows_materialize: bad arguments");
+  if (needed != nullptr && A.kind == ROWS_IM2COL3 && K == 3 * A.ld && M % A.Tlen == 0) {
+    NrProfScope ps(stream, "rows_materialize_needed[%s,Mmax=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", M, K);
+    const int n = M / A.Tlen;
+    if (dtype == NR_BF16)
+      hipLaunchKernelGGL(im2col3_title_kernel<bf16_t>, dim3(n), dim3(256), 0, stream, A, (bf16_t*)out, ldo, M, needed, n, margin);
+    else
+      hipLaunchKernelGGL(im2col3_title_kernel<float>, dim3(n), dim3(256), 0, stream, A, (float*)out, ldo, M, needed, n, margin);
+    NR_CHECK_LAUNCH();
+    return NR_OK;
+  }
   NrProfScope ps(stream, "rows_materialize[%s,M=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", M, K);
   const size_t total = (size_t)M * (K / ch);
   size_t grid = (total + 255) / 256;

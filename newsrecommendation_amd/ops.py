@@ -671,7 +671,7 @@ class ConvFunction(Function):
         db = ctx.targets[1] if direct else torch.zeros(N, dtype=torch.float32, device=dev)
         d = _lib.ConvDesc(n=n, T=T, D=D, Dp=Dp, N=N, dtype=code, table=ptr(table_p), ids=ctx.ids.data_ptr(), ids_stride=stride,
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], w_pack=ptr(w_p), bias=ptr(b_c), x_rows=ptr(ctx.x_rows),
-                          ld_rows=3 * Dp, seq_nz=seq_nz)
+                          ld_rows=3 * Dp, seq_nz=seq_nz, seq_needed=ptr(cfg.get("needed")))
         bwd_ws = _ws(_lib.lib().nr_conv_workspace_bytes(C.byref(d)), dev) if ctx.x_rows is not None else None
         d.bwd_ws, d.bwd_ws_bytes = ptr(bwd_ws), (bwd_ws.numel() * 4 if bwd_ws is not None else 0)
         check(_lib.lib().nr_conv1d_k3_bwd(C.byref(d), ptr(dy), ptr(dwp), ptr(db), _stream()), "nr_conv1d_k3_bwd")
