@@ -546,7 +546,7 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
     NR_CHECK_ARG(d->src_kind == NR_SRC_GATHER && d->p_in == 0.f && d->dtype == NR_BF16 && d->ids != nullptr && qkv == nullptr,
                  "mhsa_fwd: proj_table needs a bf16 gather source without input dropout and no qkv buffer (no backward)");
     rc = nr_launch_attn_gather_fwd(d->proj_table, d->ids, d->mask, y, d->n, d->L, d->heads, d->d_head, nr_make_drop(d->p_out, d->seed_out), s);
-    NR_CHECK_ARG(rc >= 0, "mhsa_fwd: proj_table is only supported for L <= 32, d_head %% 4 == 0, 8-byte aligned tensors");
+    NR_CHECK_ARG(rc >= 0, "mhsa_fwd: proj_table is only supported for L <= 64, d_head %% 4 == 0 (<= 32), 8-byte aligned tensors");
     return rc;
   }
   if (qkv == nullptr && d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER) {

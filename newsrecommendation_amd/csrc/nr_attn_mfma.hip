@@ -452,6 +452,18 @@ __device__ __forceinline__ void slice_load(Slice& s, const bf16_t* __restrict__ 
     if (r < L && c < d) s.v[q] = *reinterpret_cast<const bf16x4*>(src + (uint32_t)(r * ld + c));
   }
 }
+// row-indirect: token row r lives at table row ids[r] (ids points at the first token of this 32-row block)
+__device__ __forceinline__ void slice_load_g(Slice& s, const bf16_t* __restrict__ table, int ld, const int32_t* __restrict__ ids, int coff,
+                                             int L, int d, int lane) {
+  const int r = lane & 31, part = lane >> 5;
+  const bf16_t* rowp = table + (size_t)(r < L ? ids[r] : 0) * ld + coff;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * (2 * q + part);
+    s.v[q] = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    if (r < L && c < d) s.v[q] = *reinterpret_cast<const bf16x4*>(rowp + c);
+  }
+}
 template <bool DROP>
 __device__ __forceinline__ void slice_put(const Slice& s, int L, int d, bf16_t* img, int lane, const DropCfg& drop, uint32_t eidx0,
                                           uint32_t erow) {
@@ -1117,6 +1129,7 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 // Every matrix is two row-block images; queries are processed one 32-row block at a time against both key blocks.
 __device__ __forceinline__ int clampL(int L, int rb) { return min(32, max(0, L - 32 * rb)); }
 
+template <bool GATHER>
 __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1136,16 +1149,27 @@ __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
       const int head = active ? hraw : 0, Lw = active ? L : 0;
       const size_t row0 = (size_t)sb * L;
       const bf16_t* src = qkv + row0 * 3 * N + head * d;
+      // all six slices (2 row blocks x Q, K, V) are requested before the first one is written to LDS: six loads in flight
+      // per lane instead of one (the load -> wait -> ds_write chain per slice was this kernel's whole forward time)
+      Slice t[2][3];
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
-        Slice t;
         const int Lr = clampL(Lw, rb);
-        slice_load(t, src + (size_t)32 * rb * 3 * N, 3 * N, Lr, d, lane);
-        slice_put<false>(t, Lr, d, sQ + rb * IMG, lane, nodrop, 0, 0);
-        slice_load(t, src + (size_t)32 * rb * 3 * N + N, 3 * N, Lr, d, lane);
-        slice_put<false>(t, Lr, d, sK + rb * IMG, lane, nodrop, 0, 0);
-        slice_load(t, src + (size_t)32 * rb * 3 * N + 2 * N, 3 * N, Lr, d, lane);
-        slice_put<false>(t, Lr, d, sV + rb * IMG, lane, nodrop, 0, 0);
+        if (GATHER) {                                  // qkv is a [rows, 3N] table of projections, row of token r = ids[row0 + r]
+          const int32_t* idp = a.ids + row0 + 32 * rb;
+#pragma unroll
+          for (int w = 0; w < 3; ++w) slice_load_g(t[rb][w], qkv, 3 * N, idp, w * N + head * d, Lr, d, lane);
+        } else {
+#pragma unroll
+          for (int w = 0; w < 3; ++w) slice_load(t[rb][w], src + (size_t)32 * rb * 3 * N + w * N, 3 * N, Lr, d, lane);
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int Lr = clampL(Lw, rb);
+        slice_put<false>(t[rb][0], Lr, d, sQ + rb * IMG, lane, nodrop, 0, 0);
+        slice_put<false>(t[rb][1], Lr, d, sK + rb * IMG, lane, nodrop, 0, 0);
+        slice_put<false>(t[rb][2], Lr, d, sV + rb * IMG, lane, nodrop, 0, 0);
       }
       sMask[lane] = (lane < Lw) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
       __syncthreads();
@@ -1213,19 +1237,23 @@ __global__ __launch_bounds__(AW * 64) void bwd64_kernel(AttnMArgs a) {
       const int head = active ? hraw : 0, Lw = active ? L : 0;
       const size_t row0 = (size_t)sb * L;
       const bf16_t* src = qkv + row0 * 3 * N + head * d;
+      Slice t[2][4];                                   // all eight slices requested before the first LDS write (see fwd64_kernel)
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
-        Slice t;
         const int Lr = clampL(Lw, rb);
         const size_t ro = (size_t)32 * rb;
-        slice_load(t, src + ro * 3 * N, 3 * N, Lr, d, lane);
-        slice_put<false>(t, Lr, d, sQ + rb * IMG, lane, nodrop, 0, 0);
-        slice_load(t, src + ro * 3 * N + N, 3 * N, Lr, d, lane);
-        slice_put<false>(t, Lr, d, sK + rb * IMG, lane, nodrop, 0, 0);
-        slice_load(t, src + ro * 3 * N + 2 * N, 3 * N, Lr, d, lane);
-        slice_put<false>(t, Lr, d, sV + rb * IMG, lane, nodrop, 0, 0);
-        slice_load(t, dy + (row0 + ro) * N + head * d, N, Lr, d, lane);
-        slice_put<true>(t, Lr, d, sG + rb * IMG, lane, a.drop, (uint32_t)((row0 + ro) * N + head * d), (uint32_t)N);
+#pragma unroll
+        for (int w = 0; w < 3; ++w) slice_load(t[rb][w], src + ro * 3 * N + w * N, 3 * N, Lr, d, lane);
+        slice_load(t[rb][3], dy + (row0 + ro) * N + head * d, N, Lr, d, lane);
+      }
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const int Lr = clampL(Lw, rb);
+        const size_t ro = (size_t)32 * rb;
+        slice_put<false>(t[rb][0], Lr, d, sQ + rb * IMG, lane, nodrop, 0, 0);
+        slice_put<false>(t[rb][1], Lr, d, sK + rb * IMG, lane, nodrop, 0, 0);
+        slice_put<false>(t[rb][2], Lr, d, sV + rb * IMG, lane, nodrop, 0, 0);
+        slice_put<true>(t[rb][3], Lr, d, sG + rb * IMG, lane, a.drop, (uint32_t)((row0 + ro) * N + head * d), (uint32_t)N);
       }
       sMask[lane] = (lane < Lw) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
       __syncthreads();
@@ -1516,7 +1544,8 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
       NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bwd64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64));
       hipLaunchKernelGGL(bwd64_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
     } else {
-      hipLaunchKernelGGL(fwd64_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+      if (a.ids != nullptr) hipLaunchKernelGGL(fwd64_kernel<true>, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+      else hipLaunchKernelGGL(fwd64_kernel<false>, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
     }
     NR_CHECK_LAUNCH();
     return NR_OK;
@@ -1634,7 +1663,8 @@ bool nr_attn_rowsub_ok(int dtype, int L, int d_head, int heads) {
 // L <= 32, d_head % 4 == 0, 8-byte aligned).  Returns -1 when the shape has no such kernel.
 int nr_launch_attn_gather_fwd(const void* proj_table, const int32_t* ids, const float* mask, void* y, int n, int L, int heads,
                               int d_head, const DropCfg& drop, hipStream_t stream) {
-  if (!nr_attn_pad_ok(NR_BF16, L, d_head, proj_table, y) || ids == nullptr) return -1;
+  const bool long_seq = L > 32 && L <= 64 && d_head >= 4 && d_head <= 32 && d_head % 4 == 0 && ((((uintptr_t)proj_table) | ((uintptr_t)y)) & 7) == 0;
+  if ((!nr_attn_pad_ok(NR_BF16, L, d_head, proj_table, y) && !long_seq) || ids == nullptr) return -1;
   AttnMArgs a;
   a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr; a.needed = nullptr;
   a.ids = ids;

@@ -58,6 +58,19 @@ class UserEncoder(nn.Module):
         return self.attn(y)
 
 
+    @torch.no_grad()
+    def forward_indexed(self, news_table, history_idx, log_mask):
+        """Eval-time form of `forward(news_table[history_idx], log_mask)` (src/main.py:247 with src/dataset.py:68): the history
+        is given as INDICES into the [N+1, news_dim] news-vector table.  With the masked user encoder (src/demo.sh:26) Q|K|V of
+        a slot depend on its news index only, so the table is projected once and the attention gathers projected rows (the
+        title-level shortcut of ops._ProjectedTables one level up) -- no [B, H, news_dim] gather, no per-impression QKV GEMM."""
+        if not self.args.user_log_mask or ops.dtype_code(_cd(self.args)) != ops.NR_BF16 or history_idx.shape[1] > 64:
+            code = ops.dtype_code(_cd(self.args)) if self.args.user_log_mask else ops.NR_F32
+            return self.forward(ops.embed_gather(news_table, history_idx, code), log_mask)
+        y = self.multi_head_self_attn.forward_gather(history_idx, news_table, mask=log_mask)
+        return self.attn(y, log_mask)
+
+
 class Model(torch.nn.Module):
     """src/model/NRMS.py:66-95.  Also accepts the positional (args, emb, n_cat, n_subcat) call of
     src/main.py:64, which the reference class itself rejects."""

@@ -409,7 +409,7 @@ def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int, code: int, mask=None, ids=None, 
         if CHECK_INDICES:
             check_ids(ids, table.shape[0], "token id")
         N = wq.shape[0]
-        if (not torch.is_grad_enabled() and p_in == 0 and code == NR_BF16 and ids.dim() == 2 and ids.shape[1] <= 32
+        if (not torch.is_grad_enabled() and p_in == 0 and code == NR_BF16 and ids.dim() == 2 and ids.shape[1] <= 64
                 and (N // heads) % 4 == 0 and N % 8 == 0 and USE_PROJECTED_TABLE):
             return _mhsa_projected(table, (wq, bq, wk, bk, wv, bv), flat, ids.contiguous(), mask, heads, code, float(p_out))
         cfg["table_packed"] = table_cache.get(table, code)

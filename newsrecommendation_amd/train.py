@@ -220,10 +220,14 @@ def score_shard(model, news_vecs, shard: IndexedTestShard, batch_size, device):
     margs = getattr(model, "args", None)
     code = ops.dtype_code(getattr(margs, "compute_dtype", "fp32")) if getattr(margs, "user_log_mask", False) else ops.NR_F32
     batch_size = max(int(batch_size), 8192)                    # the user encoder is row-wise: bigger chunks, same vectors
+    indexed = getattr(model.user_encoder, "forward_indexed", None)                 # history as indices into the vector table
     for a in range(0, n, batch_size):
         b = min(n, a + batch_size)
-        log_vecs = ops.embed_gather(news_vecs, hist[a:b], code)                       # [B, H, news_dim], device gather
-        user[a:b] = model.user_encoder(log_vecs, mask[a:b])                           # src/main.py:247
+        if indexed is not None:
+            user[a:b] = indexed(news_vecs, hist[a:b], mask[a:b])
+        else:
+            log_vecs = ops.embed_gather(news_vecs, hist[a:b], code)                   # [B, H, news_dim], device gather
+            user[a:b] = model.user_encoder(log_vecs, mask[a:b])                       # src/main.py:247
     offsets = torch.as_tensor(shard.offsets, device=device)
     counts = shard.offsets[1:] - shard.offsets[:-1]
     imp_of = torch.repeat_interleave(torch.arange(n, dtype=torch.int32, device=device), torch.as_tensor(counts, device=device).long())

@@ -145,3 +145,26 @@ def test_eval_projected_table_shortcut_gives_the_same_news_vectors():
         ops.USE_PROJECTED_TABLE = True
     assert float((ref2 - ref).abs().max()) > 2e-3                      # the update is visible ...
     assert float((got2 - ref2).abs().max()) <= 2e-3 * float(ref2.abs().max())   # ... and the shortcut followed it
+
+
+def test_user_encoder_forward_indexed_equals_gather_then_forward():
+    """Eval: UserEncoder.forward_indexed(news_table, idx, mask) (projected news-vector table + gathering attention, L = 50) vs
+    the reference call shape user_encoder(news_table[idx], mask) -- bf16 output rounding only."""
+    import bench
+    from newsrecommendation_amd.model import NRMS
+    args = bench.make_args("bf16")
+    args.user_log_mask = True
+    torch.manual_seed(0)
+    table = torch.zeros(10, 300)
+    m = NRMS.Model(args, table.numpy()).cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    news = (torch.randn(5000, 400, generator=g) * 0.3).cuda()
+    idx = torch.randint(0, 5000, (300, 50), generator=g, dtype=torch.int32).cuda()
+    hl = torch.randint(0, 51, (300,), generator=g)
+    mask = (torch.arange(50)[None, :] >= (50 - hl)[:, None]).float().cuda()
+    with torch.no_grad():
+        ref = m.user_encoder(ops.embed_gather(news, idx), mask)
+        got = m.user_encoder.forward_indexed(news, idx, mask)
+    assert ref.shape == got.shape == (300, 400)
+    assert float((got - ref).abs().max()) <= 3e-3 * float(ref.abs().max()) + 1e-4, float((got - ref).abs().max())
+    assert float(got[hl == 0].abs().max()) == 0.0 if bool((hl == 0).any()) else True     # empty history -> exactly 0
