@@ -462,6 +462,8 @@ def main():
                     help="flat: parallel.FlatBucket (one all-reduce + fused HIP Adam); ddp: DistributedDataParallel + torch.optim.Adam")
     ap.add_argument("--deterministic", action="store_true",
                     help="ops.set_deterministic(True): fixed-point integer-atomic gradient accumulation (bit-reproducible gradients)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one rank per GPU: the measured configuration); gloo: rehearsal of the N > 1 path only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events in the timed region")
     ap.add_argument("--compact-history", action="store_true",
@@ -480,11 +482,17 @@ def main():
     dist_on = world > 1
     if a.gpus != world and dist_on:
         raise SystemExit(f"--gpus {a.gpus} != WORLD_SIZE {world}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; `--dist-backend gloo` is for rehearsing the N > 1 code path on a box with fewer GPUs than ranks
+    # (ranks then share a card and the collectives go through the host): never a measurement
+    dev_index = local_rank if a.dist_backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)   # 'nccl' == RCCL on ROCm (src/main.py:31)
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)   # 'nccl' == RCCL on ROCm (src/main.py:31)
+        else:
+            dist.init_process_group(a.dist_backend)
 
     from newsrecommendation_amd import _lib, parallel, train as TR
     from newsrecommendation_amd.model import NAML, NRMS
@@ -522,7 +530,7 @@ def main():
         # src/main.py:76 (defaults); fused=True is the same update rule in one multi-tensor kernel instead of ~6
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
         if dist_on:
-            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])   # src/main.py:82
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index])   # src/main.py:82
     if a.model == "NRMS":
         batches = synth_batches(args, a.batch, a.vocab, 4, 100 + rank, device, dense=a.dense_batch)
     else:
@@ -603,6 +611,8 @@ def main():
                           "deterministic": bool(a.deterministic),
                           "optimizer": "flat bucket + HIP fused Adam" if bucket is not None else "DDP + torch.optim.Adam(fused)",
                           "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "batch_structure": struct}}
+        if dist_on and a.dist_backend != "nccl":
+            out["config"]["rehearsal"] = f"{a.dist_backend} backend, ranks share GPUs: NOT a measurement"
         out["roofline"] = roofline_of(prof, a.dtype, struct)
         if out["roofline"] is not None:
             # the committed PMC passes profile the default (sparse, resident, non-deterministic) workload only
