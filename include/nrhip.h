@@ -358,6 +358,9 @@ int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, s
  * stream time, which adds up over the ~60 small launches of a step); on = 0: off.               */
 int nr_prof_enable(int on);
 int nr_prof_collect(char* buf, size_t n);
+/* Phase stamps of the tiled LDS-DMA NT GEMM (measurement only; option NT_ABLATE bit 64, tools/nt_trace.py): copies up to
+ * n (<= 8 * 4096) 64-bit words -- per workgroup 7 s_memrealtime stamps and the HW_ID register -- after a device sync. */
+int nr_debug_nt_trace(unsigned long long* out, int n);
 
 /* ---------------------------------------------------------------------------------------
  * The two MFMA GEMM building blocks on dense operands (used by every op above; exported for unit tests

@@ -501,7 +501,8 @@ class PoolFunction(Function):
         check(_lib.lib().nr_additive_pool_fwd(C.byref(d), ptr(e), ptr(alpha), ptr(out), N, _stream()), "nr_additive_pool_fwd")
         ctx.code, ctx.dims = code, (n, L, N, q)
         ctx.needed = needed
-        ctx.targets = tuple(grad_target(p) for p in (w1, b1, w2, b2)) if torch.is_grad_enabled() else (None,) * 4
+        # (Function.forward runs with grad mode off: no torch.is_grad_enabled() test here -- it would always say no)
+        ctx.targets = tuple(grad_target(p) for p in (w1, b1, w2, b2))
         ctx.save_for_backward(x, mask_c, w1_p, b1_c, w2_c, b2_c, e, alpha, w1)
         return out
 
@@ -555,7 +556,7 @@ class BlendFunction(Function):
         out = torch.empty(n, L, N, dtype=torch_dtype(code), device=x.device)
         check(_lib.lib().nr_pad_blend_fwd(ptr(x), ptr(mask_c), ptr(pad_c), ptr(out), n, L, N, code, _stream()), "nr_pad_blend_fwd")
         ctx.code, ctx.dims, ctx.pad_shape = code, (n, L, N), (tuple(pad.shape) if pad is not None else None)
-        ctx.pad_target = grad_target(pad) if torch.is_grad_enabled() else None
+        ctx.pad_target = grad_target(pad)
         ctx.save_for_backward(mask_c)
         return out
 
@@ -652,7 +653,7 @@ class ConvFunction(Function):
         ctx.cfg, ctx.dims = cfg, (n, T, D, Dp, N, stride)
         ctx.ids = ids                                   # keeps the (possibly strided) id view alive
         ctx.x_rows = x_rows if any(ctx.needs_input_grad[:2]) else None
-        ctx.targets = (grad_target(w), grad_target(b)) if torch.is_grad_enabled() else (None, None)
+        ctx.targets = (grad_target(w), grad_target(b))
         ctx.save_for_backward(table_p, w_p, b_c)
         return y
 
@@ -712,7 +713,7 @@ class GatherLinearFunction(Function):
                             ids=ids.data_ptr(), ids_stride=stride, w=ptr(w_p), ldw=w_p.shape[1], bias=ptr(b_c), w_t=0, ldwt=0)
         check(_lib.lib().nr_linear_fwd(C.byref(d), ptr(out), N, _stream()), "nr_linear_fwd")
         ctx.code, ctx.dims, ctx.ids = code, (M, K, N, stride, tuple(emb.shape)), ids
-        ctx.targets = tuple(grad_target(p) for p in (emb, w, b)) if torch.is_grad_enabled() else (None,) * 3
+        ctx.targets = tuple(grad_target(p) for p in (emb, w, b))
         ctx.save_for_backward(emb_p, w_p, b_c, w)
         return out
 
