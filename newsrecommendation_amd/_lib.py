@@ -100,6 +100,7 @@ SIGNATURES = {
     "nr_dropout_mask": [_vp, _u32, _f, _u32, _vp],
     "nr_prof_enable": [_i],
     "nr_prof_collect": [C.c_char_p, C.c_size_t],
+    "nr_debug_nt_trace": [_vp, _i],
 }
 
 _lib = None

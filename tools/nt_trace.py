@@ -21,9 +21,7 @@ def main():
     torch.cuda.synchronize()
     _lib.set_option("NT_ABLATE", 0)
     buf = np.zeros(8 * 4096, dtype=np.uint64)
-    fn = _lib.lib().nr_debug_nt_trace
-    fn.argtypes = [C.c_void_p, C.c_int]
-    assert fn(buf.ctypes.data, buf.size) == 0
+    assert _lib.lib().nr_debug_nt_trace(buf.ctypes.data, buf.size) == 0
     t = buf.reshape(4096, 8)
     t = t[t[:, 0] > 0]
     st = t[:, :7].astype(np.int64)
