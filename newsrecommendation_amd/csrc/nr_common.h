@@ -92,9 +92,7 @@ enum NrOpt {
   NR_OPT_ATTN_GENERIC,   // 1: no shape-specialised (L=30, 20 heads of 20) instantiation of the panel attention kernels
   NR_OPT_NO_ROW_SUB,     // 1: the projection writes the bias into padding rows (bias_rows) instead of per-row substitution
   NR_OPT_ATTN_BWD_OCC4,  // 1: the specialised attention backward built for 4 waves per SIMD (128 VGPRs, a few spills) instead of 3
-  NR_OPT_NT_ABLATE,      // measurement only (results are WRONG): LDS-DMA NT kernel without 1: output stores, 2: MFMAs, 4: operand DMA, 8: epilogue
-  NR_OPT_NT_DIRECT_EPI,  // 0: the packed bf16 epilogue of the LDS-DMA NT kernel goes through an LDS image; 1: registers -> global
-  NR_OPT_NT_PERSIST,     // 1: bf16-output LDS-DMA NT GEMMs run as the persistent kernel (tile boundary overlapped)
+  NR_OPT_NT_ABLATE,      // measurement only (results are WRONG): tiled LDS-DMA NT kernel without 1: output stores, 2: MFMAs, 4: operand DMA, 8: epilogue; 64: phase stamps (nr_debug_nt_trace)
   NR_OPT_NT_WREG,        // 1 (default): skinny-K bf16 NT GEMMs with the weights held in registers (persistent, LDS ring of activation rows); 2: the same in 4-wave workgroups, two per CU; 0: tile kernels
   NR_OPT_COUNT
 };

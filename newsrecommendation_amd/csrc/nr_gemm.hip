@@ -1037,7 +1037,6 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
     if (p < DBM / 16) {
       int arow = min(m0 + 16 * p + prow, M - 1);
       if (compact) arow = ep.row_idx[arow];        // compacted row -> row of A
-      if (abl & 128) arow = 16 * p + prow;         // timing experiment (wrong results): every tile reads the first rows (L2 hits)
       src[t] = A + (size_t)arow * lda + c8;
       isA[t] = true;
     } else {
@@ -1050,13 +1049,6 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
     for (int t = 0; t < PB + 1; ++t) {
       if (t < PB || extra) {
         const int kk = isA[t] ? min(k0, K - 8 - c8) : k0;   // K tail of A: re-read a valid chunk (B is zero there)
-        if (abl & 32) {
-          // timing experiment (wrong results): whole 128-byte lines -- 8 rows x 128 B per piece, the other 8 rows on the next stage
-          const int p = pfirst + t, half = (k0 >> 5) & 1, r8 = (lane >> 3) + 8 * half, kq = (k0 >> 6) * 64 + (lane & 7) * 8;
-          const bf16_t* sp = isA[t] ? A + (size_t)min(m0 + 16 * p + r8, M - 1) * lda + min(kq, K - 8)
-                                    : B + (size_t)min(nbase + 16 * (p - DBM / 16) + r8, Ntot - 1) * ldb + min(kq, K - 8);
-          dma16(sp, lds0 + stage * STAGE + (pfirst + t) * 1024);
-        } else
         if (!(abl & 4)) dma16(src[t] + kk, lds0 + stage * STAGE + (pfirst + t) * 1024);
       }
     }
@@ -1134,7 +1126,6 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
     // DMA lead (stage kt+1 must have landed at step kt).
     bf16x8 fa[2][4], fb[2][HN];
     auto load_frags = [&](int buf, int stage) {
-      if (abl & 256) return;
       const char* st = smem + stage * STAGE;
 #pragma unroll
       for (int i = 0; i < 4; ++i) fa[buf][i] = *reinterpret_cast<const bf16x8*>(st + offA[i]);
@@ -1208,106 +1199,6 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
   nt_stamp(abl, 3);
   if (abl & 8) {
     if (acc[0][0][0] == 12345.678f) ((float*)ep.C)[0] = acc[1][0][1];   // keeps the loop alive
-    return;
-  }
-  if (PK && (abl & 16)) {
-    // direct epilogue: no LDS image, no barrier.  A lane owns 4 consecutive columns of a row in every 16-column tile
-    // (8 bytes of bf16); v_permlane16_swap pairs two neighbouring tiles so that it stores 16 bytes and a store
-    // instruction covers 64 contiguous bytes of each of its 16 rows.
-    bf16_t* Cb = (bf16_t*)ep.C;
-    const float* sG = reinterpret_cast<const float*>(smem + NS * STAGE);
-    const float* sAl = reinterpret_cast<const float*>(smem + NS * STAGE + GBYTES);
-    const int g = lane >> 4;
-    bf16_t* rowp[4];
-    bool mok[4];
-    float rs4[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* grow4[4] = {nullptr, nullptr, nullptr, nullptr};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ml = wm * 64 + i * 16 + (lane & 15), m = m0 + ml;
-      mok[i] = m < M;
-      const int mout = !compact ? m : (r_lds ? reinterpret_cast<const int*>(smem + NS * STAGE + 1024)[ml] : (mok[i] ? ep.row_idx[m] : 0));
-      rowp[i] = Cb + (size_t)mout * ep.ldc + nbase;
-      if (EPI == EPI_POOLBWD && mok[i]) {
-        if (g_lds && m0 + 255 < M) rs4[i] = sAl[ml]; else rs4[i] = ep.rowscale[m];
-        grow4[i] = g_lds ? sG + (m / ep.L - t0) * WBN : ep.G + (size_t)(m / ep.L) * ep.ldg + nbase;
-      }
-    }
-    const bool gvec = g_lds || ((EPI == EPI_POOLBWD) && (ep.ldg % 4 == 0) && (nbase % 4 == 0) && (((uintptr_t)ep.G & 15) == 0));
-    const bool al16 = (ep.ldc % 8) == 0 && (nbase % 8) == 0;
-    auto bias4 = [&](int jt) {
-      const int nl = jt * 16 + 4 * g;
-      f32x4 bvec = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if ((EPI == EPI_STORE || EPI == EPI_STORE_TANH) && ep.bias != nullptr) {
-        if (b_lds && nl + 4 <= N) {
-          bvec = *reinterpret_cast<const f32x4*>(sG + nl);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (nl + r < N) bvec[r] = ep.bias[nbase + nl + r];
-        }
-      }
-      return bvec;
-    };
-    auto packed = [&](f32x4 v, const f32x4& bvec, int i, int jt) {
-      const int nl = jt * 16 + 4 * g;
-      v = v + bvec;
-      if (EPI == EPI_STORE_TANH) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-      }
-      if (EPI == EPI_POOLBWD && grow4[i] != nullptr) {
-        if (gvec && nl + 4 <= N) {
-          const f32x4 gq = *reinterpret_cast<const f32x4*>(grow4[i] + nl);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += rs4[i] * gq[r];
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (nl + r < N) v[r] += rs4[i] * grow4[i][nl + r];
-        }
-      }
-      const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-      return __builtin_bit_cast(uint2, o);
-    };
-#pragma unroll
-    for (int j = 0; j < HN; j += 2) {
-      const int jt0 = wn * HN + j;
-      if (jt0 < NT16) {
-        constexpr int J1MAX = HN - 1;
-        const int j1 = j + 1 <= J1MAX ? j + 1 : j;
-        const bool pair = (j + 1 < HN) && (jt0 + 1 < NT16);        // wave-uniform
-        const f32x4 b0 = bias4(jt0), b1 = bias4(pair ? jt0 + 1 : jt0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          uint2 x = packed(acc[i][j], b0, i, jt0);
-          if (pair) {
-            uint2 y = packed(acc[i][j1], b1, i, jt0 + 1);
-            const auto s0 = __builtin_amdgcn_permlane16_swap(x.x, y.x, false, false);
-            const auto s1 = __builtin_amdgcn_permlane16_swap(x.y, y.y, false, false);
-            const int col = (jt0 + (g & 1)) * 16 + (g >> 1) * 8;
-            if (mok[i]) {
-              if (col + 8 <= N && al16) {
-                *reinterpret_cast<uint4*>(rowp[i] + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-              } else {
-                const uint32_t w[4] = {s0[0], s1[0], s0[1], s1[1]};
-                for (int e = 0; e < 8 && col + e < N; ++e) rowp[i][col + e] = __builtin_bit_cast(bf16_t, (uint16_t)(w[e >> 1] >> (16 * (e & 1))));
-              }
-            }
-          } else {
-            const int col = jt0 * 16 + 4 * g;
-            if (mok[i]) {
-              if (col + 4 <= N && (ep.ldc % 4) == 0 && (nbase % 4) == 0) {
-                *reinterpret_cast<uint2*>(rowp[i] + col) = x;
-              } else {
-                const uint32_t w[2] = {x.x, x.y};
-                for (int e = 0; e < 4 && col + e < N; ++e) rowp[i][col + e] = __builtin_bit_cast(bf16_t, (uint16_t)(w[e >> 1] >> (16 * (e & 1))));
-              }
-            }
-          }
-        }
-      }
-    }
     return;
   }
   if (PK) {
@@ -1453,339 +1344,6 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
   }
 }
 
-// =========================================================================================
-// Persistent flavour of the LDS-DMA NT kernel for bf16 outputs.  One launch fills the chip once
-// (gridDim = 8 XCDs x workgroups per XCD) and every workgroup walks a strided list of
-// (row tile, column chunk) tiles of its XCD -- the chunks of a row tile are neighbours in that
-// list, so the A tile is read from HBM once and from the XCD's L2 afterwards.  The point is the
-// tile boundary: the epilogue goes from the accumulators straight to global memory (no LDS
-// image, v_permlane16_swap pairs two 16-column tiles into 16-byte lane stores), so the ring is
-// free while it runs and the first operand stage of the NEXT tile is already on its way --
-// pipeline fill, store drain and workgroup launch of the one-tile-per-workgroup kernel
-// (together about half of its time at K = 304) overlap instead of adding up.
-// =========================================================================================
-template <int EPI, int NT16, int WM>
-__global__ __launch_bounds__(128 * WM) void gemm_nt_pers_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
-                                                                int ldb, int M, int Ntot, int K, EpiArgs ep, int nchunks, int tiles_m) {
-  constexpr int DBM = 64 * WM, NW = 2 * WM, WTHR = 128 * WM;
-  constexpr int WBN = NT16 * 16;
-  constexpr int NP = DBM / 16 + NT16;
-  constexpr int PB = NP / NW, PX = NP % NW;
-  constexpr int STAGE = NP * 1024;
-  constexpr int NS = dma_ring_stages(STAGE, WM);
-  constexpr int AB = DBM * 64;
-  constexpr int HN = (NT16 + 1) / 2;
-  constexpr int GT = 12, GBYTES = ((GT * WBN * 4 + 1023) / 1024) * 1024;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wid >> 1, wn = wid & 1;
-  const bool extra = wid < PX;
-  const int pfirst = wid * PB + min(wid, PX);
-  const int prow = lane >> 2, c8 = ((lane & 3) ^ swzP(prow)) * 8;
-  const int g = lane >> 4, fr = lane & 15;
-
-  const bool compact = (EPI == EPI_STORE) && ep.row_count != nullptr;
-  if (compact) M = *ep.row_count;
-  const bool tile_flags = ep.seq_nz != nullptr && !compact;
-  const bool zero_ok = (ep.ldc & 7) == 0;        // POOLBWD: rows of all-zero tiles are written as 16-byte zero stores
-
-  // tiles of this XCD: row tiles 8q + x, all column chunks of a row tile next to each other
-  const int x = blockIdx.x & 7, stride = gridDim.x >> 3;
-  const int nq = x < tiles_m ? (tiles_m - x + 7) / 8 : 0, ntl = nq * nchunks;
-
-  struct Tile { int m0, nbase, N, t0; bool b_lds, r_lds, g_lds; };
-  auto tile_of = [&](int t) {
-    Tile T;
-    const int q = t / nchunks, nch = t - q * nchunks;
-    T.m0 = (8 * q + x) * DBM; T.nbase = nch * WBN; T.N = min(WBN, Ntot - T.nbase);
-    T.t0 = (EPI == EPI_POOLBWD) ? T.m0 / max(ep.L, 1) : 0;
-    T.b_lds = (EPI == EPI_STORE || EPI == EPI_STORE_TANH) && ep.bias != nullptr && (T.nbase % 4 == 0) && T.N >= 4 && (((uintptr_t)ep.bias & 15) == 0);
-    T.r_lds = (EPI == EPI_STORE) && compact && M >= 4 && (((uintptr_t)ep.row_idx & 15) == 0) && T.m0 + DBM - 1 < M;
-    T.g_lds = (EPI == EPI_POOLBWD) && ep.L >= DBM / (GT - 2) && (ep.ldg % 4 == 0) && (T.nbase % 4 == 0) && (((uintptr_t)ep.G & 15) == 0) &&
-              (((uintptr_t)ep.rowscale & 15) == 0) && M >= 4;
-    return T;
-  };
-  // first tile at or after t (in steps of `stride`) that has work; all-zero POOLBWD tiles are zero-filled on the way
-  auto find_live = [&](int t) {
-    for (; t < ntl; t += stride) {
-      const Tile T = tile_of(t);
-      if (T.m0 >= M) return ntl;                 // row tiles ascend with t: nothing further either
-      if (!tile_flags) return t;
-      const int t_first = T.m0 / ep.L, t_last = (min(T.m0 + DBM, M) - 1) / ep.L;
-      bool live = false;
-      for (int u = t_first + tid; u <= t_last; u += WTHR) live |= ep.seq_nz[u] != 0;
-      const bool fill = EPI == EPI_POOLBWD;
-      if (fill && !((T.N & 7) == 0 && zero_ok && (T.nbase & 7) == 0)) live = true;
-      if (__syncthreads_or(live)) return t;
-      if (fill) {
-        const int cpr = T.N / 8;
-        for (int u = tid; u < DBM * cpr; u += WTHR) {
-          const int row = u / cpr, c = (u - row * cpr) * 8;
-          if (T.m0 + row < M) *reinterpret_cast<uint4*>((bf16_t*)ep.C + (size_t)(T.m0 + row) * ep.ldc + T.nbase + c) = make_uint4(0, 0, 0, 0);
-        }
-      }
-    }
-    return ntl;
-  };
-
-  const bf16_t* src[PB + 1];
-  bool isA[PB + 1];
-#pragma unroll
-  for (int t = 0; t < PB + 1; ++t) isA[t] = pfirst + t < DBM / 16;
-  auto set_src = [&](const Tile& T) {
-#pragma unroll
-    for (int t = 0; t < PB + 1; ++t) {
-      const int p = pfirst + t;
-      if (p < DBM / 16) {
-        int arow = min(T.m0 + 16 * p + prow, M - 1);
-        if (compact) arow = ep.row_idx[arow];
-        src[t] = A + (size_t)arow * lda + c8;
-      } else {
-        src[t] = B + (size_t)min(T.nbase + 16 * (p - DBM / 16) + prow, Ntot - 1) * ldb + c8;
-      }
-    }
-  };
-  auto issue = [&](int stage, int k0) {
-#pragma unroll
-    for (int t = 0; t < PB + 1; ++t) {
-      if (t < PB || extra) {
-        const int kk = isA[t] ? min(k0, K - 8 - c8) : k0;
-        dma16(src[t] + kk, lds0 + stage * STAGE + (pfirst + t) * 1024);
-      }
-    }
-  };
-  // per-tile operands of the epilogue, parked behind the ring
-  auto issue_extras = [&](const Tile& T) {
-    if (T.b_lds && wid == NW - 1) dma16(ep.bias + T.nbase + min(4 * lane, ((T.N - 4) / 4) * 4), lds0 + NS * STAGE);
-    if (T.r_lds && wid == NW - 2 && lane < DBM / 4) dma16(ep.row_idx + T.m0 + 4 * lane, lds0 + NS * STAGE + 1024);
-    if (T.g_lds) {
-      const int tlast = (M - 1) / ep.L;
-      for (int p = wid; p < GBYTES / 1024; p += NW) {
-        const int u = 64 * p + lane, tt = u / (WBN / 4), c4 = u - tt * (WBN / 4);
-        const float* gsrc = ep.G + (size_t)min(T.t0 + tt, tlast) * ep.ldg + T.nbase + min(4 * c4, max(T.N - 4, 0));
-        dma16(gsrc, lds0 + NS * STAGE + p * 1024);
-      }
-      if (wid == NW - 1 && lane < DBM / 4) dma16(ep.rowscale + min(T.m0 + 4 * lane, M - 4), lds0 + NS * STAGE + GBYTES);
-    }
-  };
-  auto wait_stages = [&](int stages) {
-    if (extra) {
-      if (stages >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PB + 1)) : "memory");
-      else if (stages == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB + 1) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if (stages >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PB) : "memory");
-      else if (stages == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PB) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  };
-
-  int offA[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wm * 64 + i * 16 + fr;
-    offA[i] = r * 64 + ((g ^ swzP(r)) << 4);
-  }
-  const int offB = AB + wn * HN * 1024 + fr * 64 + ((g ^ swzP(fr)) << 4);
-  const int nk = (K + BK - 1) / BK;
-
-  int t = find_live(blockIdx.x >> 3);
-  if (t >= ntl) return;
-  Tile cur = tile_of(t);
-  set_src(cur);
-  issue_extras(cur);
-#pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) issue(s, s * BK);
-
-  for (;;) {
-    f32x4 acc[4][HN];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < HN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    constexpr bool PF = (NS == 4) && (HN <= 7);
-    if constexpr (PF) {
-      bf16x8 fa[2][4], fb[2][HN];
-      auto load_frags = [&](int buf, int stage) {
-        const char* st = smem + stage * STAGE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[buf][i] = *reinterpret_cast<const bf16x8*>(st + offA[i]);
-#pragma unroll
-        for (int j = 0; j < HN; ++j)
-          if (wn * HN + j < NT16) fb[buf][j] = *reinterpret_cast<const bf16x8*>(st + offB + j * 1024);
-      };
-      auto mfmas = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < HN; ++j) {
-          if (wn * HN + j < NT16) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0);
-          }
-        }
-      };
-      auto step = [&](int kt, int cb) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): see gemm_nt_dma_kernel
-        if (kt + 1 < nk) {
-          wait_stages(min(NS - 3, nk - 2 - kt));
-          __builtin_amdgcn_s_barrier();
-          if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
-          load_frags(cb ^ 1, (kt + 1) % NS);
-        }
-        mfmas(cb);
-      };
-      wait_stages(min(NS - 2, nk - 1));
-      __builtin_amdgcn_s_barrier();
-      load_frags(0, 0);
-      int kt = 0;
-      for (; kt + 1 < nk; kt += 2) {
-        step(kt, 0);
-        step(kt + 1, 1);
-      }
-      if (kt < nk) step(kt, 0);
-    } else {
-      for (int kt = 0; kt < nk; ++kt) {
-        wait_stages(min(NS - 2, nk - 1 - kt));
-        __builtin_amdgcn_s_barrier();
-        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, (kt + NS - 1) * BK);
-        const char* st = smem + (kt % NS) * STAGE;
-        bf16x8 af[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + offA[i]);
-#pragma unroll
-        for (int j = 0; j < HN; ++j) {
-          if (wn * HN + j < NT16) {
-            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(st + offB + j * 1024);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
-          }
-        }
-      }
-    }
-    // every DMA of this tile has landed (the last wait was vmcnt(0)); the barrier frees the ring
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int tn = find_live(t + stride);
-    const bool has_next = tn < ntl;
-    Tile nxt = cur;
-    if (has_next) {
-      nxt = tile_of(tn);
-      set_src(nxt);
-      issue(0, 0);                               // in flight while the epilogue stores
-    }
-
-    // ---- epilogue of `cur`: accumulators -> global
-    {
-      const Tile& T = cur;
-      bf16_t* Cb = (bf16_t*)ep.C;
-      const float* sG = reinterpret_cast<const float*>(smem + NS * STAGE);
-      const float* sAl = reinterpret_cast<const float*>(smem + NS * STAGE + GBYTES);
-      bf16_t* rowp[4];
-      bool mok[4];
-      float rs4[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* grow4[4] = {nullptr, nullptr, nullptr, nullptr};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ml = wm * 64 + i * 16 + fr, m = T.m0 + ml;
-        mok[i] = m < M;
-        const int mout = !compact ? m : (T.r_lds ? reinterpret_cast<const int*>(smem + NS * STAGE + 1024)[ml] : (mok[i] ? ep.row_idx[m] : 0));
-        rowp[i] = Cb + (size_t)mout * ep.ldc + T.nbase;
-        if (EPI == EPI_POOLBWD && mok[i]) {
-          if (T.g_lds && T.m0 + DBM - 1 < M) rs4[i] = sAl[ml]; else rs4[i] = ep.rowscale[m];
-          grow4[i] = T.g_lds ? sG + (m / ep.L - T.t0) * WBN : ep.G + (size_t)(m / ep.L) * ep.ldg + T.nbase;
-        }
-      }
-      const bool gvec = T.g_lds || ((EPI == EPI_POOLBWD) && (ep.ldg % 4 == 0) && (T.nbase % 4 == 0) && (((uintptr_t)ep.G & 15) == 0));
-      const bool al16 = (ep.ldc % 8) == 0 && (T.nbase % 8) == 0;
-      const int N = T.N;
-      auto bias4 = [&](int jt) {
-        const int nl = jt * 16 + 4 * g;
-        f32x4 bvec = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if ((EPI == EPI_STORE || EPI == EPI_STORE_TANH) && ep.bias != nullptr) {
-          if (T.b_lds && nl + 4 <= N) {
-            bvec = *reinterpret_cast<const f32x4*>(sG + nl);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (nl + r < N) bvec[r] = ep.bias[T.nbase + nl + r];
-          }
-        }
-        return bvec;
-      };
-      auto packed = [&](f32x4 v, const f32x4& bvec, int i, int jt) {
-        const int nl = jt * 16 + 4 * g;
-        v = v + bvec;
-        if (EPI == EPI_STORE_TANH) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-        }
-        if (EPI == EPI_POOLBWD && grow4[i] != nullptr) {
-          if (gvec && nl + 4 <= N) {
-            const f32x4 gq = *reinterpret_cast<const f32x4*>(grow4[i] + nl);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += rs4[i] * gq[r];
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (nl + r < N) v[r] += rs4[i] * grow4[i][nl + r];
-          }
-        }
-        const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        return __builtin_bit_cast(uint2, o);
-      };
-#pragma unroll
-      for (int j = 0; j < HN; j += 2) {
-        const int jt0 = wn * HN + j;
-        if (jt0 < NT16) {
-          const int j1 = j + 1 < HN ? j + 1 : j;
-          const bool pair = (j + 1 < HN) && (jt0 + 1 < NT16);        // wave-uniform
-          const f32x4 b0 = bias4(jt0), b1 = bias4(pair ? jt0 + 1 : jt0);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            uint2 xv = packed(acc[i][j], b0, i, jt0);
-            if (pair) {
-              uint2 yv = packed(acc[i][j1], b1, i, jt0 + 1);
-              const auto s0 = __builtin_amdgcn_permlane16_swap(xv.x, yv.x, false, false);
-              const auto s1 = __builtin_amdgcn_permlane16_swap(xv.y, yv.y, false, false);
-              const int col = (jt0 + (g & 1)) * 16 + (g >> 1) * 8;
-              if (mok[i]) {
-                if (col + 8 <= N && al16) {
-                  *reinterpret_cast<uint4*>(rowp[i] + col) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                } else {
-                  const uint32_t w[4] = {s0[0], s1[0], s0[1], s1[1]};
-                  for (int e = 0; e < 8 && col + e < N; ++e)
-                    rowp[i][col + e] = __builtin_bit_cast(bf16_t, (uint16_t)(w[e >> 1] >> (16 * (e & 1))));
-                }
-              }
-            } else {
-              const int col = jt0 * 16 + 4 * g;
-              if (mok[i]) {
-                if (col + 4 <= N && (ep.ldc % 4) == 0 && (T.nbase % 4) == 0) {
-                  *reinterpret_cast<uint2*>(rowp[i] + col) = xv;
-                } else {
-                  const uint32_t w[2] = {xv.x, xv.y};
-                  for (int e = 0; e < 4 && col + e < N; ++e)
-                    rowp[i][col + e] = __builtin_bit_cast(bf16_t, (uint16_t)(w[e >> 1] >> (16 * (e & 1))));
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-    if (!has_next) break;
-    __syncthreads();                             // every wave has read cur's bias / row numbers / G rows out of LDS
-    issue_extras(nxt);
-#pragma unroll
-    for (int s = 1; s < NS - 1; ++s)
-      if (s < nk) issue(s, s * BK);
-    cur = nxt;
-    t = tn;
-  }
-}
-
 }  // namespace
 extern "C" int nr_debug_nt_trace(unsigned long long* out, int n) {
   if (out == nullptr || n <= 0) return NR_ERR_ARG;
@@ -1794,33 +1352,6 @@ extern "C" int nr_debug_nt_trace(unsigned long long* out, int n) {
   return NR_OK;
 }
 namespace {
-template <int EPI, int NT16, int WM>
-int launch_nt_pers(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
-  constexpr int DBM = 64 * WM, NP = DBM / 16 + NT16, STAGE = NP * 1024, NS = dma_ring_stages(STAGE, WM);
-  constexpr size_t ring = (size_t)NS * STAGE;
-  constexpr size_t gtile = EPI == EPI_POOLBWD ? (size_t)((12 * NT16 * 16 * 4 + 1023) / 1024) * 1024 + 1024 : 2048;
-  constexpr size_t smem = ring + gtile;
-  auto kern = gemm_nt_pers_kernel<EPI, NT16, WM>;
-  NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    NR_CHECK_HIP(hipGetDevice(&dev));
-    NR_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
-    cus = n > 0 ? n : 256;
-  }
-  const int tilesM = (M + DBM - 1) / DBM, nchunks = (N + NT16 * 16 - 1) / (NT16 * 16);
-  const int per_cu = WM == 4 ? 1 : 2;
-  const int tiles_xcd = ((tilesM + 7) / 8) * nchunks;
-  int per_xcd = (cus / 8) * per_cu;
-  if (per_xcd < 1) per_xcd = 1;
-  if (per_xcd > tiles_xcd) per_xcd = tiles_xcd;
-  hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(128 * WM), smem, stream, (const bf16_t*)A.base, A.ld, (const bf16_t*)B, ldb, M, N, K, ep,
-                     nchunks, tilesM);
-  NR_CHECK_LAUNCH();
-  return NR_OK;
-}
-
 // =========================================================================================
 // NT with the WEIGHTS IN REGISTERS (bf16 in, bf16 out; K <= 32 * KS; EPI_STORE / EPI_STORE_TANH).
 // For the skinny-K projections (QKV: N = 1200, K = 304) the tile kernels above spend their time
@@ -1860,23 +1391,39 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {   // n is wave-uniform
   }
 }
 
-template <int TPW, int KS>
+// MODE of the weights-in-registers kernel: how a workgroup finds its row blocks
+enum { WREG_DENSE = 0,    // blocks b0 + k * stride of the dense rows
+       WREG_COMPACT = 1,  // the same over the compacted live rows (ep.row_count / ep.row_idx); row numbers ride with the stages
+       WREG_LIST = 2 };   // dense rows, but only blocks that touch a sequence flagged in ep.seq_nz (list built in the prologue)
+
+template <int EPI, int TPW, int KS, int RT, int MODE>
 struct WregCfg {
-  static constexpr int R = 16, NW = 8, NS = 8;
-  static constexpr int GCOLS = NW * TPW * 16;
+  static constexpr int NW = 8, R = 16 * RT;
+  static constexpr int GCOLS = NW * TPW * 16;                         // columns of a group
+  static constexpr int APIECES = RT * KS;                             // 1-KB pieces: 16 rows x 64 B per (row tile, k-step)
+  static constexpr int RIDER = MODE == WREG_COMPACT ? 1 : 0;          // row numbers
+  static constexpr int GT = 3, GP = (GCOLS * 4 + 1023) / 1024;        // POOLBWD: pooled-gradient rows of up to GT sequences
+  static constexpr int PBW = EPI == EPI_POOLBWD ? 1 + GT * GP : 0;    //          alpha of the block's rows + those G rows
+  static constexpr int PIECES = APIECES + RIDER + PBW;
+  static constexpr int PW = (PIECES + NW - 1) / NW;                   // DMAs per wave and stage
+  static constexpr int STAGE = PIECES * 1024;
+  static constexpr int NS0 = (132 * 1024) / STAGE;
+  static constexpr int NS = NS0 > 8 ? 8 : NS0;                        // ring depth
+  static constexpr int S = RT * ((TPW + 1) / 2);                      // stores per wave and step
+  static constexpr int DUMP = NS * STAGE, BIAS = DUMP + NW * 1024, LIST = BIAS + GCOLS * 4;
+  static_assert(NS >= 3, "stage too large for the LDS ring");
+  static_assert((NS - 2) * PW + (NS - 1) * S <= 62, "vmcnt is a 6-bit counter");
 };
 
-template <int EPI, int TPW, int KS, bool COMPACT, int NW>
-__global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_nt_wreg_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
+template <int EPI, int TPW, int KS, int RT, int MODE>
+__global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
                                                            int Mmax, int Ntot, int K, EpiArgs ep, int ngroups) {
-  constexpr int R = 16, NS = NW == 8 ? 8 : 6;
-  constexpr int PIECES = KS + (COMPACT ? 1 : 0);       // 1-KB DMA pieces of a stage: KS k-steps of 16 rows x 64 B (+ the row-number rider)
-  constexpr int PW = (PIECES + NW - 1) / NW;           // DMAs per wave and stage
-  constexpr int STAGE = PIECES * 1024;
-  constexpr int S = (TPW + 1) / 2;                     // stores per wave and step
-  constexpr int GCOLS = NW * TPW * 16;
-  constexpr int DUMP = NS * STAGE, BIAS = DUMP + NW * 1024;
-  static_assert((NS - 2) * PW + (NS - 1) * S <= 62, "vmcnt is a 6-bit counter");
+  using Cfg = WregCfg<EPI, TPW, KS, RT, MODE>;
+  constexpr int NW = Cfg::NW, R = Cfg::R, NS = Cfg::NS, PW = Cfg::PW, STAGE = Cfg::STAGE, S = Cfg::S, GCOLS = Cfg::GCOLS;
+  constexpr int APIECES = Cfg::APIECES, GT = Cfg::GT, GP = Cfg::GP;
+  constexpr bool COMPACT = MODE == WREG_COMPACT, LISTED = MODE == WREG_LIST, PB = EPI == EPI_POOLBWD;
+  constexpr int P_RIDER = APIECES;                       // piece index of the row-number rider (COMPACT)
+  constexpr int P_ALPHA = APIECES + Cfg::RIDER;          // POOLBWD: alpha piece, then GT * GP pieces of G rows
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1890,58 +1437,107 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_nt_wreg_kernel(const bf1
   const int x = blockIdx.x & 7, j = blockIdx.x >> 3, Q = (gridDim.x >> 3) / ngroups;
   const int grp = j % ngroups, q = j / ngroups;
   const int b0 = q * 8 + x, bstride = 8 * Q;
-  const int nsteps = b0 < nblk ? (nblk - b0 + bstride - 1) / bstride : 0;
+  int nsteps = b0 < nblk ? (nblk - b0 + bstride - 1) / bstride : 0;
   if (nsteps == 0) return;
-  auto blk = [&](int k) { return b0 + k * bstride; };
-  // (the host launches this instantiation only when K needs exactly KS k-steps of 32)
+  const int gcol0 = grp * GCOLS, wcol0 = gcol0 + wid * TPW * 16;
+  int* sList = reinterpret_cast<int*>(smem + Cfg::LIST);
+  if (LISTED) {
+    // ordered list of this workgroup's blocks that touch a flagged sequence
+    __shared__ int sCnt[NW + 1];
+    const int cand = nsteps;
+    int run = 0;
+    for (int base = 0; base < cand; base += 512) {
+      const int c = base + tid, b = b0 + c * bstride;
+      bool live = false;
+      if (c < cand) {
+        const int t0 = (b * R) / ep.L, t1 = (min(b * R + R, M) - 1) / ep.L;
+        for (int t = t0; t <= t1; ++t) live |= ep.seq_nz[t] != 0;
+      }
+      const uint64_t bal = __ballot(live);
+      if (lane == 0) sCnt[wid] = __popcll(bal);
+      __syncthreads();
+      int before = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const int cw = sCnt[w];
+        before += w < wid ? cw : 0;
+        total += cw;
+      }
+      if (live) sList[run + before + __popcll(bal & ((1ull << lane) - 1ull))] = b;
+      run += total;
+      __syncthreads();
+    }
+    nsteps = run;
+    if (nsteps == 0) return;                        // (POOLBWD: the zeros of such blocks come from zero_dead_blocks_kernel)
+  }
+  auto blk = [&](int k) {
+    if (LISTED) return k < nsteps ? sList[k] : 0;
+    return b0 + k * bstride;
+  };
 
   // ---- this wave's slice of the weights: TPW column tiles x K, resident in registers
-  const int gcol0 = grp * GCOLS, wcol0 = gcol0 + wid * TPW * 16;
   bf16x8 bfr[TPW][KS];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int n = min(wcol0 + t * 16 + fr, Ntot - 1);
     const bf16_t* brow = B + (size_t)n * ldb + 8 * g;
 #pragma unroll
-    for (int s2 = 0; s2 < KS; ++s2) {
-      bfr[t][s2] = *reinterpret_cast<const bf16x8*>(brow + 32 * s2);
-    }
+    for (int s2 = 0; s2 < KS; ++s2) bfr[t][s2] = *reinterpret_cast<const bf16x8*>(brow + 32 * s2);
   }
   // bias of the group's columns (zeros without one): the accumulators START from it
-  float* sBias = reinterpret_cast<float*>(smem + BIAS);
-  for (int c = tid; c < GCOLS; c += 64 * NW) sBias[c] = (ep.bias != nullptr && gcol0 + c < Ntot) ? ep.bias[gcol0 + c] : 0.f;
+  float* sBias = reinterpret_cast<float*>(smem + Cfg::BIAS);
+  for (int c = tid; c < GCOLS; c += 512) sBias[c] = (!PB && ep.bias != nullptr && gcol0 + c < Ntot) ? ep.bias[gcol0 + c] : 0.f;
   // the compiler must not carry "weights still loading" into the loop (it would wait with vmcnt(0) there every step)
   __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+  if (LISTED) __syncthreads();                   // the list is complete
 
-  // ---- stage issue: every wave exactly PW DMAs
-  const uint32_t dump_lds = lds0 + DUMP + wid * 1024;
-  auto issue_stage = [&](int kk, int arow) {
+  // ---- stage issue: every wave exactly PW DMAs (surplus ones into its dump piece)
+  const uint32_t dump_lds = lds0 + Cfg::DUMP + wid * 1024;
+  auto issue_stage = [&](int kk, const int (&arow)[RT]) {
     const uint32_t slot = lds0 + (kk % NS) * STAGE;
     const bool real = kk < nsteps;
-    const bf16_t* rowp = A + (size_t)arow * lda;
+    const int bk = real ? blk(kk) : 0;
 #pragma unroll
     for (int u = 0; u < PW; ++u) {
       const int p = wid + NW * u;                  // wave-uniform
-      if (real && p < KS) {
-        dma16(rowp + min(32 * p + c8, K - 8), slot + p * 1024);
-      } else if (COMPACT && real && p == KS) {
-        // rider: lanes 0-3 the row numbers of this block, lanes 4-7 those of the block NS-1 steps ahead
-        const int bb = lane < 4 ? blk(kk) : blk(kk + NS - 1);
-        const int e = min(bb * R + 4 * (lane & 3), Mmax - 4);
-        dma16(ep.row_idx + (lane < 8 ? e : 0), slot + p * 1024);
+      if (real && p < APIECES) {
+        const int i = p / KS, s2 = p - i * KS;
+        int ar = arow[0];
+#pragma unroll
+        for (int ii = 1; ii < RT; ++ii) ar = i == ii ? arow[ii] : ar;
+        dma16(A + (size_t)ar * lda + min(32 * s2 + c8, K - 8), slot + p * 1024);
+      } else if (COMPACT && real && p == P_RIDER) {
+        // rider: the row numbers of this block (R ints), then those of the block NS-1 steps ahead (R ints)
+        const int half = lane / (R / 4), bb = half == 0 ? bk : blk(kk + NS - 1);
+        const int e = min(bb * R + 4 * (lane % (R / 4)), Mmax - 4);
+        dma16(ep.row_idx + (lane < R / 2 ? e : 0), slot + p * 1024);
+      } else if (PB && real && p == P_ALPHA) {
+        dma16(ep.rowscale + min(bk * R + 4 * (lane % (R / 4)), Mmax - 4), slot + p * 1024);
+      } else if (PB && real && p > P_ALPHA && p < P_ALPHA + 1 + GT * GP) {
+        // pooled-gradient row of sequence t0 + tt, columns of this group: GP pieces of 256 floats
+        const int u2 = p - P_ALPHA - 1, tt = u2 / GP, part = u2 - tt * GP;
+        const int t = min((bk * R) / ep.L + tt, (Mmax - 1) / ep.L);
+        const int col = min(gcol0 + part * 256 + 4 * lane, Ntot - 4);
+        dma16(ep.G + (size_t)t * ep.ldg + col, slot + p * 1024);
       } else {
-        dma16(rowp + c8, dump_lds);
+        dma16(A + c8, dump_lds);
       }
     }
   };
-  // A row this lane fetches for block kk (prologue: from global memory; steady state: from the rider)
-  auto arow_global = [&](int kk) {
-    const int row = blk(kk) * R + prow;
-    if (kk >= nsteps || row >= M) return 0;
-    return COMPACT ? ep.row_idx[row] : row;
+  // A rows this lane fetches for block kk (prologue: straight from global memory; steady state: from the rider)
+  auto arows_global = [&](int kk, int (&arow)[RT]) {
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int row = blk(kk) * R + 16 * i + prow;
+      arow[i] = (kk >= nsteps || row >= M) ? 0 : (COMPACT ? ep.row_idx[row] : row);
+    }
   };
 #pragma unroll 1
-  for (int kk = 0; kk < NS - 1; ++kk) issue_stage(kk, arow_global(kk));
+  for (int kk = 0; kk < NS - 1; ++kk) {
+    int ar[RT];
+    arows_global(kk, ar);
+    issue_stage(kk, ar);
+  }
 
   const int offA = fr * 64 + ((g ^ swzP(fr)) << 4);
   bf16_t* Cb = (bf16_t*)ep.C;
@@ -1952,68 +1548,104 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void gemm_nt_wreg_kernel(const bf1
     wait_vmcnt_le((NS - 2) * PW + min(k, NS - 1) * S);
     __builtin_amdgcn_s_barrier();                  // stage k is in LDS for everyone; everyone is done with stage k-1
     const char* st = smem + (k % NS) * STAGE;
-    // next stage to fetch (slot of stage k-1)
-    int arow_next, mout;
-    const int b = blk(k), m = b * R + fr;
-    if (COMPACT) {
-      const int* rid = reinterpret_cast<const int*>(st + KS * 1024);
-      const int rown = blk(k + NS - 1) * R + prow;
-      arow_next = (k + NS - 1 < nsteps && rown < M) ? rid[R + prow] : 0;
-      mout = rid[fr];
-    } else {
-      const int rown = blk(k + NS - 1) * R + prow;
-      arow_next = (k + NS - 1 < nsteps && rown < M) ? rown : 0;
-      mout = m;
-    }
-    issue_stage(k + NS - 1, arow_next);
-
-    f32x4 acc[TPW];
+    const int b = blk(k);
+    int ar[RT], mout[RT];
+    {
+      const int bn = blk(k + NS - 1);
+      const int* rid = reinterpret_cast<const int*>(st + P_RIDER * 1024);
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = *reinterpret_cast<const f32x4*>(sBias + (wid * TPW + t) * 16 + 4 * g);
+      for (int i = 0; i < RT; ++i) {
+        const int rown = bn * R + 16 * i + prow;
+        const bool ok = k + NS - 1 < nsteps && rown < M;
+        ar[i] = !ok ? 0 : (COMPACT ? rid[R + 16 * i + prow] : rown);
+        mout[i] = COMPACT ? rid[16 * i + fr] : b * R + 16 * i + fr;
+      }
+    }
+    issue_stage(k + NS - 1, ar);
+
+    f32x4 acc[RT][TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + (wid * TPW + t) * 16 + 4 * g);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) acc[i][t] = bv;
+    }
     if (wcol0 < Ntot) {                            // wave-uniform: a wave whose tiles are all beyond N only keeps step with the others
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(st + s2 * 1024 + offA);
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][s2], af, acc[t], 0, 0, 0);
+        for (int i = 0; i < RT; ++i) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(st + (i * KS + s2) * 1024 + offA);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][s2], af, acc[i][t], 0, 0, 0);
+        }
       }
     }
     // ---- epilogue: exactly S stores per wave
-    const bool rok = m < M;
-    bf16_t* crow = Cb + (size_t)mout * ep.ldc;
-    auto pack4 = [&](f32x4 v) {
-      if (EPI == EPI_STORE_TANH) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+    for (int i = 0; i < RT; ++i) {
+      const int m = b * R + 16 * i + fr;
+      const bool rok = m < M;
+      bf16_t* crow = Cb + (size_t)mout[i] * ep.ldc;
+      float al = 0.f;
+      const float* grow = nullptr;
+      if (PB) {
+        // C = acc + alpha[m] * G[m / L][col]: alpha and the G rows of the block's (at most GT) sequences came with the stage
+        const int t0 = (b * R) / ep.L, r0 = m - t0 * ep.L;
+        const int tt = (r0 >= ep.L ? 1 : 0) + (r0 >= 2 * ep.L ? 1 : 0);
+        al = reinterpret_cast<const float*>(st + P_ALPHA * 1024)[16 * i + fr];
+        grow = reinterpret_cast<const float*>(st + (P_ALPHA + 1 + tt * GP) * 1024);
       }
-      const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-      return __builtin_bit_cast(uint2, o);
-    };
+      auto pack4 = [&](f32x4 v, int lcol) {
+        if (EPI == EPI_STORE_TANH) {
 #pragma unroll
-    for (int t = 0; t < TPW; t += 2) {
-      if (t + 1 < TPW) {
-        const uint2 xv = pack4(acc[t]), yv = pack4(acc[t + 1 < TPW ? t + 1 : t]);
-        const auto s0 = __builtin_amdgcn_permlane16_swap(xv.x, yv.x, false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(xv.y, yv.y, false, false);
-        const int col = wcol0 + (t + (g & 1)) * 16 + (g >> 1) * 8;
-        uint4* dst = (rok && col + 8 <= Ntot) ? reinterpret_cast<uint4*>(crow + col) : dump_g;
-        *dst = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-      } else {
-        const uint2 xv = pack4(acc[t]);
-        const int col = wcol0 + t * 16 + 4 * g;
-        uint2* dst = (rok && col + 4 <= Ntot) ? reinterpret_cast<uint2*>(crow + col) : reinterpret_cast<uint2*>(dump_g);
-        *dst = xv;
+          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+        }
+        if (PB) {
+          const f32x4 gq = *reinterpret_cast<const f32x4*>(grow + lcol);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += al * gq[r];
+        }
+        const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        return __builtin_bit_cast(uint2, o);
+      };
+#pragma unroll
+      for (int t = 0; t < TPW; t += 2) {
+        const int lc = (wid * TPW + t) * 16 + 4 * g;         // this lane's first column inside the group, tile t
+        if (t + 1 < TPW) {
+          const uint2 xv = pack4(acc[i][t], lc), yv = pack4(acc[i][t + 1 < TPW ? t + 1 : t], lc + 16);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(xv.x, yv.x, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(xv.y, yv.y, false, false);
+          const int col = wcol0 + (t + (g & 1)) * 16 + (g >> 1) * 8;
+          uint4* dst = (rok && col + 8 <= Ntot) ? reinterpret_cast<uint4*>(crow + col) : dump_g;
+          *dst = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        } else {
+          const uint2 xv = pack4(acc[i][t], lc);
+          const int col = wcol0 + t * 16 + 4 * g;
+          uint2* dst = (rok && col + 4 <= Ntot) ? reinterpret_cast<uint2*>(crow + col) : reinterpret_cast<uint2*>(dump_g);
+          *dst = xv;
+        }
       }
     }
   }
 }
 
-template <int EPI, int TPW, int KS, int NW>
-int launch_nt_wreg_n(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
-  constexpr int NS = NW == 8 ? 8 : 6, GCOLS = NW * TPW * 16;
-  const bool compact = ep.row_count != nullptr;
-  const int pieces = KS + (compact ? 1 : 0);
-  const size_t smem = (size_t)NS * pieces * 1024 + NW * 1024 + GCOLS * sizeof(float);
+// POOLBWD with sequence flags: rows of blocks no flagged sequence touches are zeros -- written by this store-only kernel
+__global__ __launch_bounds__(256) void zero_dead_blocks_kernel(const int32_t* __restrict__ seq_nz, int L, int M, int R, uint4* __restrict__ C,
+                                                               int row_chunks) {
+  const int b = blockIdx.x;
+  const int t0 = (b * R) / L, t1 = (min(b * R + R, M) - 1) / L;
+  bool live = false;
+  for (int t = t0; t <= t1; ++t) live |= seq_nz[t] != 0;     // uniform
+  if (live) return;
+  const int rows = min(R, M - b * R);
+  uint4* dst = C + (size_t)b * R * row_chunks;
+  for (int u = threadIdx.x; u < rows * row_chunks; u += 256) dst[u] = make_uint4(0, 0, 0, 0);
+}
+
+template <int EPI, int TPW, int KS, int RT, int MODE>
+int launch_nt_wreg_m(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
+  using Cfg = WregCfg<EPI, TPW, KS, RT, MODE>;
   static int cus = 0;
   if (cus == 0) {
     int dev = 0, n = 0;
@@ -2021,29 +1653,23 @@ int launch_nt_wreg_n(const RowSrc& A, const void* B, int ldb, int M, int N, int 
     NR_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
     cus = n >= 8 ? n : 256;
   }
-  const int ngroups = (N + GCOLS - 1) / GCOLS;
-  int Q = (cus / 8) * (8 / NW) / ngroups;        // workgroups per XCD and group: 8 waves per CU in all
+  const int ngroups = (N + Cfg::GCOLS - 1) / Cfg::GCOLS;
+  int Q = (cus / 8) / ngroups;                   // workgroups per XCD and group: one workgroup per CU
   if (Q < 1) Q = 1;
-  const int nblk = (M + 15) / 16, qmax = (nblk + 7) / 8;
+  const int nblk = (M + Cfg::R - 1) / Cfg::R, qmax = (nblk + 7) / 8;
   if (Q > qmax) Q = qmax;
-  const dim3 grid(8 * ngroups * Q);
-  if (compact) {
-    auto kern = gemm_nt_wreg_kernel<EPI, TPW, KS, true, NW>;
-    NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, stream, (const bf16_t*)A.base, A.ld, (const bf16_t*)B, ldb, M, N, K, ep, ngroups);
-  } else {
-    auto kern = gemm_nt_wreg_kernel<EPI, TPW, KS, false, NW>;
-    NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(kern, grid, dim3(64 * NW), smem, stream, (const bf16_t*)A.base, A.ld, (const bf16_t*)B, ldb, M, N, K, ep, ngroups);
+  const int max_steps = (nblk + 8 * Q - 1) / (8 * Q);
+  const size_t smem = (size_t)Cfg::LIST + (MODE == WREG_LIST ? (size_t)(max_steps + 8) * sizeof(int) : 0);
+  NR_CHECK_ARG(smem <= 160 * 1024, "gemm_nt_wreg: %d row blocks per workgroup do not fit the LDS list", max_steps);
+  auto kern = gemm_nt_wreg_kernel<EPI, TPW, KS, RT, MODE>;
+  NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  if (EPI == EPI_POOLBWD && MODE == WREG_LIST) {
+    hipLaunchKernelGGL(zero_dead_blocks_kernel, dim3(nblk), dim3(256), 0, stream, ep.seq_nz, ep.L, M, Cfg::R, (uint4*)ep.C, ep.ldc / 8);
   }
+  hipLaunchKernelGGL(kern, dim3(8 * ngroups * Q), dim3(512), smem, stream, (const bf16_t*)A.base, A.ld, (const bf16_t*)B, ldb, M, N, K, ep,
+                     ngroups);
   NR_CHECK_LAUNCH();
   return NR_OK;
-}
-template <int EPI, int TPW, int KS>
-int launch_nt_wreg(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
-  // NR_NT_WREG = 2: 4-wave workgroups, two per CU (own barriers: the two waves of a SIMD drift apart and fill each other's gaps)
-  if (nr_opt(NR_OPT_NT_WREG) == 2) return launch_nt_wreg_n<EPI, TPW, KS, 4>(A, B, ldb, M, N, K, ep, stream);
-  return launch_nt_wreg_n<EPI, TPW, KS, 8>(A, B, ldb, M, N, K, ep, stream);
 }
 
 template <int EPI, int NT16, bool PK, int WM>
@@ -2054,15 +1680,12 @@ int launch_nt_dma_w(const RowSrc& A, const void* B, int ldb, int M, int N, int K
   constexpr size_t gtile = EPI == EPI_POOLBWD && PK ? (size_t)((12 * NT16 * 16 * 4 + 1023) / 1024) * 1024 + 1024
                                                     : ((EPI == EPI_SCATTER || EPI == EPI_STORE) ? 2048 : 1024);
   constexpr size_t smem0 = ring > epi ? ring : epi, smem1 = smem0 > epk ? smem0 : epk, smem = smem1 + gtile;
-  if constexpr (PK && EPI != EPI_SCATTER) {
-    if (nr_opt(NR_OPT_NT_PERSIST)) return launch_nt_pers<EPI, NT16, WM>(A, B, ldb, M, N, K, ep, stream);
-  }
   auto kern = gemm_nt_dma_kernel<EPI, NT16, PK, WM>;
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   const int tilesM = (M + DBM - 1) / DBM, nchunks = (N + NT16 * 16 - 1) / (NT16 * 16);
   const int grid = ((tilesM + 7) / 8) * 8 * nchunks;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * WM), smem, stream, (const bf16_t*)A.base, A.ld, (const bf16_t*)B, ldb, M, N, K, ep,
-                     nchunks | ((nr_opt(NR_OPT_NT_ABLATE) | (nr_opt(NR_OPT_NT_DIRECT_EPI) ? 16 : 0)) << 16));
+                     nchunks | (nr_opt(NR_OPT_NT_ABLATE) << 16));
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -2662,11 +2285,26 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
     NrProfScope ps(stream, ep.row_count ? "gemm_nt_dma_live[bf16,epi=%d,Mmax=%d,N=%d,K=%d]"
                                         : (tile_skip ? "gemm_nt_dma_needed[bf16,epi=%d,Mmax=%d,N=%d,K=%d]" : "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d]"),
                    epi, M, N, K);
-    // skinny K, wide N, bf16 out: weights-in-registers kernel (QKV projection)
-    if (nr_opt(NR_OPT_NT_WREG) && (epi == EPI_STORE || epi == EPI_STORE_TANH) && ep.out_dtype == NR_BF16 && !tile_skip && K <= 320 &&
-        K > 288 && N >= 320 && N % 8 == 0 && ep.ldc % 8 == 0 && M >= 16 && (ep.row_count == nullptr || (M >= 4 && ((uintptr_t)ep.row_idx & 15) == 0))) {
-      return epi == EPI_STORE ? launch_nt_wreg<EPI_STORE, 5, 10>(A, B, ldb, M, N, K, ep, stream)
-                              : launch_nt_wreg<EPI_STORE_TANH, 5, 10>(A, B, ldb, M, N, K, ep, stream);
+    // skinny K, bf16 out: weights-in-registers kernels (see gemm_nt_wreg_kernel); shapes with an instantiation:
+    //   QKV projection    STORE       K in (288, 320], N >= 320        5 column tiles per wave, 16-row steps
+    //   pooling fc1       STORE_TANH  K in (384, 416], N <= 256        2 column tiles per wave, 32-row steps
+    //   pooling dX        POOLBWD     K in (192, 224], N <= 512        4 column tiles per wave, 32-row steps
+    if (nr_opt(NR_OPT_NT_WREG) && ep.out_dtype == NR_BF16 && N % 8 == 0 && ep.ldc % 8 == 0 && M >= 64 && ldb >= kr32 &&
+        (ep.row_count == nullptr || (((uintptr_t)ep.row_idx & 15) == 0 && M % 4 == 0))) {
+      const bool flags = ep.seq_nz != nullptr && ep.row_count == nullptr && ep.L >= 16;
+      if (epi == EPI_STORE && !tile_skip && K > 288 && K <= 320 && N >= 320) {
+        return ep.row_count ? launch_nt_wreg_m<EPI_STORE, 5, 10, 1, WREG_COMPACT>(A, B, ldb, M, N, K, ep, stream)
+                            : launch_nt_wreg_m<EPI_STORE, 5, 10, 1, WREG_DENSE>(A, B, ldb, M, N, K, ep, stream);
+      }
+      if (epi == EPI_STORE_TANH && ep.row_count == nullptr && K > 384 && K <= 416 && N <= 256 && (!tile_skip || flags)) {
+        return tile_skip ? launch_nt_wreg_m<EPI_STORE_TANH, 2, 13, 2, WREG_LIST>(A, B, ldb, M, N, K, ep, stream)
+                         : launch_nt_wreg_m<EPI_STORE_TANH, 2, 13, 2, WREG_DENSE>(A, B, ldb, M, N, K, ep, stream);
+      }
+      if (epi == EPI_POOLBWD && ep.row_count == nullptr && K > 192 && K <= 224 && N <= 512 && ep.L >= 16 && ep.ldg % 4 == 0 &&
+          (((uintptr_t)ep.G | (uintptr_t)ep.rowscale) & 15) == 0 && M % 4 == 0 && (ep.seq_nz == nullptr || flags)) {
+        return ep.seq_nz ? launch_nt_wreg_m<EPI_POOLBWD, 4, 7, 2, WREG_LIST>(A, B, ldb, M, N, K, ep, stream)
+                         : launch_nt_wreg_m<EPI_POOLBWD, 4, 7, 2, WREG_DENSE>(A, B, ldb, M, N, K, ep, stream);
+      }
     }
     const int c13 = ((N + 207) / 208) * 13, c20 = ((N + 319) / 320) * 20;   // fewer padded column tiles wins
     if (c13 < c20) return launch_nt_dma_e<13>(A, B, ldb, M, N, K, epi, ep, stream);
