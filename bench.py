@@ -162,9 +162,27 @@ def price_kernel(label, avg_ms, struct, dtype):
         if name.endswith("_live"):
             M = M * (struct["live_gradient_slabs"] if name.startswith("gemm_tn") else struct["live_token_rows"])
         elif name.endswith("_needed"):
-            M = M * struct.get("needed_tiles", 1.0)              # row tiles with at least one needed title
+            # row tiles (128 rows) / 32-row blocks (weights-in-registers kernels) with at least one needed title
+            M = M * (struct["live_gradient_slabs"] if name.startswith("gemm_nt_wreg") else struct.get("needed_tiles", 1.0))
         fl = 2.0 * M * N * K
         peak = PEAK_MFMA_BF16 if "bf16" in label else PEAK_MFMA_F32
+        # the skinny GEMMs of this path sit near the ridge (K = 200..400: ~200-300 FLOP per byte of activations moved): price
+        # the launch against BOTH roofs and report the one that binds.  Bytes: the activation rows read + the rows written
+        # (weights are a few hundred KB); "Mfull" = rows written even where nothing is computed (pooling dX writes zeros).
+        ge = 2 if "bf16" in label else 4
+        epi = _dims(label, r"epi=(\d+)")
+        epi = epi[0] if epi else 0
+        if name.startswith("gemm_tn"):
+            by = M * (N + K) * ge                                 # both operands are activations, the output is a weight gradient
+        elif epi == 2:
+            by = M * K * ge + M * N * 4                           # + fp32 atomic rows (upper bound: before run merging)
+        elif epi == 1:
+            by = M * K * ge + d[0] * N * ge
+        else:
+            by = M * (K + N) * ge
+        t_mfma, t_hbm = fl / (peak * 1e12), by / (PEAK_HBM * 1e9)
+        if t_hbm > t_mfma:
+            return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}
         return {"bound": "mfma", "achieved": round(fl / s / 1e12, 2), "peak": peak, "unit": "TFLOP/s", "work": fl}
     if name.startswith("attn") or name.startswith("mhsa_fused"):
         d = _dims(label, r"n=(\d+),L=(\d+),h=(\d+),d=(\d+)")
@@ -211,13 +229,13 @@ def pmc_traffic(label):
     pm = pmc_file()
     if pm is None:
         return None
-    key = {"gemm_nt[": "gemm_nt_kernelIDF16bLi0ELi0", "gemm_nt_dma": "gemm_nt_dma_kernel", "gemm_tn2": "tn2::gemm_tn2_kernel", "gemm_tn3": "tn3::gemm_tn3_kernel",
+    key = {"gemm_nt[": "gemm_nt_kernelIDF16bLi0ELi0", "gemm_nt_dma": "gemm_nt_dma_kernel", "gemm_nt_wreg": "gemm_nt_wreg_kernel", "gemm_tn2": "tn2::gemm_tn2_kernel", "gemm_tn3": "tn3::gemm_tn3_kernel",
            "attn_mfma_bwd": "b16::bwd_kernel", "attn_mfma_fwd": "b16::fwd_kernel", "gemm_nt_wide": "gemm_nt_wide_kernel",
            "mhsa_fused_fwd": "fused_fwd", "mhsa_fused_bwd": "fused_bwd"}
     want = next((v for k, v in key.items() if label.startswith(k)), None)
     if want is None:
         return None
-    if label.startswith("gemm_nt_dma") and "epi=" in label:      # one instantiation per epilogue: <EPI, NT16, PK>
+    if (label.startswith("gemm_nt_dma") or label.startswith("gemm_nt_wreg")) and "epi=" in label:      # one instantiation per epilogue: <EPI, ...>
         want += "<" + label.split("epi=")[1].split(",")[0] + ","
     for k in pm["kernels"]:
         if want in k["kernel"]:

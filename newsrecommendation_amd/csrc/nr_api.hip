@@ -42,7 +42,7 @@ struct OptDef { const char* name; int def; };
 const OptDef g_opt_defs[NR_OPT_COUNT] = {
     {"NO_SLABS", 0},   {"NO_ATTN_SKIP", 0}, {"SIDE_STREAM", 0}, {"ATTN_OLD", 0},  {"ATTN_VALU", 0},   {"NO_PAD_SUB", 0},
     {"NO_FUSED_FWD", 0}, {"NO_TN3", 0},     {"TN_V1", 0},       {"TN3_ROUNDS", 0}, {"TN3_WK", 0},      {"TN3_NI", 0},
-    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}, {"NO_ROW_SUB", 0}, {"ATTN_BWD_OCC4", 0}, {"NT_ABLATE", 0}, {"NT_WREG", 1}};
+    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}, {"NO_ROW_SUB", 0}, {"ATTN_BWD_OCC4", 0}, {"NT_ABLATE", 0}, {"NT_WREG", 1}, {"NO_SCATTER_SORT", 0}};
 std::atomic<int> g_opt[NR_OPT_COUNT];
 std::once_flag g_opt_once;
 void opt_init() {
@@ -279,15 +279,19 @@ static int mhsa_rows(const nr_mhsa_desc* d, RowSrc* out) {
 // row_ws (int32): [0,4) counters | M live rows | M their ids | M padding rows | n per-sequence live-token masks |
 //                 slab scratch: n title flags, 4 counters, M/32 slab ids, 4 pad | sequence list: 4 counters, n entries
 struct MhsaWs {
-  size_t live_idx, live_ids, dead_idx, tmask, slab, seq, total;   // offsets in int32 elements
+  size_t live_idx, live_ids, dead_idx, tmask, slab, seq, sort_idx, sort_ids, hist, total;   // offsets in int32 elements
 };
-static MhsaWs mhsa_ws_layout(int n, int L) {
+// table_rows > 0 (gather source): room for the live rows sorted by token id (table-gradient scatter) and its histogram
+static MhsaWs mhsa_ws_layout(int n, int L, int table_rows) {
   const size_t M = (size_t)n * L;
   MhsaWs w;
   w.live_idx = 4; w.live_ids = 4 + M; w.dead_idx = 4 + 2 * M; w.tmask = 4 + 3 * M;
   w.slab = w.tmask + n;
   w.seq = w.slab + n + 4 + M / 32 + 4;
-  w.total = w.seq + 4 + n + 4;
+  w.sort_idx = (w.seq + 4 + n + 4 + 3) / 4 * 4;                      // 16-byte aligned: the GEMM stages these lists by DMA
+  w.sort_ids = w.sort_idx + (table_rows > 0 ? (M + 3) / 4 * 4 : 0);
+  w.hist = w.sort_ids + (table_rows > 0 ? (M + 3) / 4 * 4 : 0);
+  w.total = w.hist + (table_rows > 0 ? (size_t)table_rows + 8 : 0);
   return w;
 }
 // bwd_ws of the convolution (int32): n title flags | 4 counters | M/32 slab ids | pad
@@ -323,9 +327,9 @@ static int mhsa_check(const nr_mhsa_desc* d) {
   NR_CHECK_ARG(d->n == 0 || (d->x && d->w_qkv && d->b_qkv), "mhsa: null operand");
   NR_CHECK_ARG(d->p_in >= 0.f && d->p_in < 1.f && d->p_out >= 0.f && d->p_out < 1.f, "mhsa: dropout p out of range");
   NR_CHECK_ARG((uint64_t)d->n * d->L * (uint64_t)(3 * d->heads * d->d_head) < 0xffffffffull, "mhsa: problem too large for 32-bit element counters");
-  NR_CHECK_ARG(d->row_ws == nullptr || d->row_ws_bytes >= mhsa_ws_layout(d->n, d->L).total * sizeof(int32_t),
+  NR_CHECK_ARG(d->row_ws == nullptr || d->row_ws_bytes >= mhsa_ws_layout(d->n, d->L, d->src_kind == NR_SRC_GATHER ? d->table_rows : 0).total * sizeof(int32_t),
                "mhsa: row_ws holds %zu bytes, nr_mhsa_workspace_bytes() asks for %zu", d->row_ws_bytes,
-               mhsa_ws_layout(d->n, d->L).total * sizeof(int32_t));
+               mhsa_ws_layout(d->n, d->L, d->src_kind == NR_SRC_GATHER ? d->table_rows : 0).total * sizeof(int32_t));
   return NR_OK;
 }
 
@@ -412,7 +416,7 @@ int nr_get_option(const char* name) {
 }
 
 size_t nr_mhsa_workspace_bytes(const nr_mhsa_desc* d) {
-  return (d == nullptr || d->n < 0 || d->L < 1) ? 0 : mhsa_ws_layout(d->n, d->L).total * sizeof(int32_t);
+  return (d == nullptr || d->n < 0 || d->L < 1) ? 0 : mhsa_ws_layout(d->n, d->L, d->src_kind == NR_SRC_GATHER ? d->table_rows : 0).total * sizeof(int32_t);
 }
 size_t nr_conv_workspace_bytes(const nr_conv_desc* d) {
   return (d == nullptr || d->n < 0 || d->T < 1) ? 0 : conv_ws_elems(d->n, d->T) * sizeof(int32_t);
@@ -537,7 +541,7 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   NR_DEVICE_GUARD(stream, y);
   const int N = d->heads * d->d_head, M = d->n * d->L, Kp = round_up(d->d_model, nr_chunk(d->dtype));
-  const MhsaWs W = mhsa_ws_layout(d->n, d->L);
+  const MhsaWs W = mhsa_ws_layout(d->n, d->L, d->src_kind == NR_SRC_GATHER ? d->table_rows : 0);
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
   if (d->proj_table != nullptr) {
@@ -589,7 +593,9 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   const int32_t* fwd_list = nullptr;
   if (d->seq_needed != nullptr && tmask != nullptr && ((size_t)d->L * N * nr_elt_size(d->dtype)) % 16 == 0 && (((uintptr_t)y) & 15) == 0) {
     int32_t* lw = d->row_ws + W.seq;
-    if ((rc = nr_launch_needed_list(d->seq_needed, d->n, lw, y, (size_t)d->L * N * nr_elt_size(d->dtype), s))) return rc;
+    if ((rc = nr_launch_needed_list(d->seq_needed, d->n, lw, y, (size_t)d->L * N * nr_elt_size(d->dtype), s,
+                                    d->needed_no_fill ? 32 / d->L + 2 : -1)))
+      return rc;
     fwd_list = lw;
   }
   return nr_launch_attn(false, d->dtype, qkv, d->mask, y, nullptr, nullptr, d->n, d->L, d->heads, d->d_head,
@@ -606,7 +612,7 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
   hipStream_t s = (hipStream_t)stream;
   NR_DEVICE_GUARD(stream, dqkv);
   const int N = d->heads * d->d_head, M = d->n * d->L, ch = nr_chunk(d->dtype), Kp = round_up(d->d_model, ch);
-  const MhsaWs W = mhsa_ws_layout(d->n, d->L);
+  const MhsaWs W = mhsa_ws_layout(d->n, d->L, d->src_kind == NR_SRC_GATHER ? d->table_rows : 0);
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
   // row_ws_ready: the forward compacted the rows and (when the attention kernels support it) left the qkv rows of
@@ -684,6 +690,15 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
         // only rows with a non-padding token id reach the table gradient: compact them, GEMM over those alone
         if (!d->row_ws_ready && (rc = nr_launch_compact_rows(d->ids, 1, M, d->row_ws, s))) return rc;
         ep.row_count = d->row_ws; ep.row_idx = d->row_ws + W.live_idx; ep.row_ids = d->row_ws + W.live_ids;
+        if (d->table_rows > 0 && !nr_opt(NR_OPT_NO_SCATTER_SORT)) {
+          // ... in token-id order: occurrences of one word become neighbours, the scatter epilogue adds them up in
+          // registers and issues one atomic row per run instead of one per occurrence (memory-side fp32 atomics run at
+          // ~1.3 TB/s chip-wide; a MIND-shaped batch repeats each word ~9 times)
+          if ((rc = nr_launch_sort_rows_by_id(d->row_ws, ep.row_idx, ep.row_ids, M, d->table_rows, d->row_ws + W.hist,
+                                              d->row_ws + W.sort_idx, d->row_ws + W.sort_ids, s)))
+            return rc;
+          ep.row_idx = d->row_ws + W.sort_idx; ep.row_ids = d->row_ws + W.sort_ids;
+        }
       }
       rc = nr_launch_gemm_nt(d->dtype, G, w_qkv_t, ldwt, M, d->d_model, 3 * N, EPI_SCATTER, ep, s);
     } else {

@@ -94,6 +94,7 @@ enum NrOpt {
   NR_OPT_ATTN_BWD_OCC4,  // 1: the specialised attention backward built for 4 waves per SIMD (128 VGPRs, a few spills) instead of 3
   NR_OPT_NT_ABLATE,      // measurement only (results are WRONG): tiled LDS-DMA NT kernel without 1: output stores, 2: MFMAs, 4: operand DMA, 8: epilogue; 64: phase stamps (nr_debug_nt_trace)
   NR_OPT_NT_WREG,        // 1 (default): skinny-K bf16 NT GEMMs with the weights held in registers (persistent, LDS ring of activation rows); 2: the same in 4-wave workgroups, two per CU; 0: tile kernels
+  NR_OPT_NO_SCATTER_SORT, // 1: the table-gradient GEMM walks the live rows in batch order instead of token-id order
   NR_OPT_COUNT
 };
 int nr_opt(int which);
@@ -193,6 +194,22 @@ int nr_fix_flush(const NrFixTable* t, hipStream_t s);      // out[i] += fix[i] *
 int nr_det_open(hipStream_t s, float* base0, size_t n0, float* base1, size_t n1, bool gemm, bool pool, int* rc);
 int nr_det_close(int handle);
 
+#ifdef __HIPCC__
+// pieces of nr_accum for callers that sum several contributions before the atomic: the sum must then be taken in fixed
+// point too (integer addition is associative, fp32 addition is not)
+__device__ __forceinline__ long long nr_to_fix(float x) { return __float2ll_rn(x * 68719476736.0f); }
+__device__ __forceinline__ void nr_accum_fix(float* p, long long q) {       // deterministic mode only
+  const int cnt = g_nr_fix.count;
+  for (int i = 0; i < cnt; ++i) {
+    const unsigned long long idx = (unsigned long long)(p - g_nr_fix.base[i]);
+    if (p >= g_nr_fix.base[i] && idx < g_nr_fix.n[i]) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(g_nr_fix.fix[i] + idx), (unsigned long long)q);
+      return;
+    }
+  }
+  atomicAdd(p, (float)q * (1.0f / 68719476736.0f));     // not a registered output (does not happen: DetScope lists them all)
+}
+#endif
 // ---- small device helpers ----------------------------------------------------------------
 template <typename T> struct EltTraits;
 template <> struct EltTraits<float> { static constexpr int CH = 4; static constexpr int DT = NR_F32; };

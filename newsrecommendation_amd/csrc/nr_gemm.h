@@ -58,6 +58,10 @@ int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, i
                                const int32_t* needed = nullptr, int margin = 0);
 // ws: int32 [2*M + 4] -> ws[0] = number of rows with ids[m*stride] != 0, ws[4 ..] their row numbers, ws[4 + M ..] their ids
 int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* ws, hipStream_t stream);
+// live rows (count on the device, their row numbers and token ids) -> the same rows grouped by token id (counting sort:
+// hist int32 [table_rows + 8] scratch).  Order inside a group is arbitrary.
+int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const int32_t* ids, int Mmax, int table_rows, int32_t* hist,
+                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream);
 // forward flavour: ws int32 [3*M + n + 4] (adds ws[1] = dead count, ws[2] = "table row 0 is not zero", ws[4+2M ..] dead rows,
 // ws[4+3M ..] per-sequence live-token bit masks when L <= 32)
 int nr_launch_compact_rows_fwd(const int32_t* ids, int M, int n, int L, const void* table_row0, int cols, int32_t* ws,
@@ -69,7 +73,7 @@ int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_
 int nr_launch_title_flags(const void* dy, int n, int L, int N, int32_t* title_nz, hipStream_t stream);
 int nr_launch_row_flags_f32(const float* g, int ld, int N, int n, int32_t* nz, hipStream_t stream);
 int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream);
-int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream);
+int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream, int fill_margin = -1);
 int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream);
 int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K,
                             int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream);

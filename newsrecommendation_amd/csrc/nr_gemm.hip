@@ -1288,6 +1288,79 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
     nt_stamp(abl, 6);
     return;
   }
+  if constexpr (EPI == EPI_SCATTER) {
+    // table-gradient scatter, 64 rows (one wave row) at a time through the fp32 LDS tile.  A wave owns 64 / NW consecutive
+    // rows with its lanes on CONSECUTIVE floats (an atomic instruction covers whole 128-byte lines of the destination
+    // row; float4-per-lane ownership spread every instruction over 8 lines).  Rows that follow each other with the SAME
+    // token id -- the caller hands the rows over sorted by id -- are summed in registers and leave as one atomic row:
+    // memory-side float atomics run at ~1.3 TB/s chip-wide, one atomic row per occurrence was half of this kernel.
+    constexpr int RPW = 64 / NW, NC = (WBN + 63) / 64;
+    static_assert((size_t)64 * SCW * sizeof(float) <= (size_t)NS * STAGE, "scatter tile must fit the ring");
+#pragma unroll 1
+    for (int pass = 0; pass < WM; ++pass) {
+      if (pass) __syncthreads();
+      if (wm == pass) {
+#pragma unroll
+        for (int j = 0; j < HN; ++j) {
+          const int jt = wn * HN + j;
+          if (jt < NT16) {
+            const int col = jt * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sC[(i * 16 + (lane >> 4) * 4 + r) * SCW + col] = acc[i][j][r];
+          }
+        }
+      }
+      __syncthreads();
+      float run[NC];
+      long long runq[NC];                            // deterministic mode: the run is summed in fixed point (order independent)
+#pragma unroll
+      for (int u = 0; u < NC; ++u) { run[u] = 0.f; runq[u] = 0; }
+      int run_id = 0;
+      auto flush = [&]() {
+        if (run_id != 0) {                           // padding_idx row receives no gradient
+          float* dst = (float*)ep.C + (size_t)run_id * ep.ldc + nbase;
+#pragma unroll
+          for (int u = 0; u < NC; ++u) {
+            const int c = lane + 64 * u;
+            if (c < N && nbase + c < ep.Dtrue) {
+              if (det) { if (runq[u] != 0) nr_accum_fix(dst + c, runq[u]); }
+              else if (run[u] != 0.f) atomicAdd(dst + c, run[u]);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NC; ++u) { run[u] = 0.f; runq[u] = 0; }
+      };
+      const bool from_lds = i_lds && m0 + DBM - 1 < M;
+      for (int q = 0; q < RPW; ++q) {
+        const int rr = wid * RPW + q, mloc = pass * 64 + rr, m = m0 + mloc;
+        if (m >= M) break;
+        const int id = from_lds ? reinterpret_cast<const int*>(smem + NS * STAGE)[mloc]
+                                : (compact ? ep.row_ids[m] : ep.ids[(size_t)m * ep.ids_stride]);
+        if (id != run_id) {
+          flush();
+          run_id = id;
+        }
+        if (id == 0) continue;
+        // the dropout counter follows the ORIGINAL row
+        const int morig = !compact ? m : (from_lds ? reinterpret_cast<const int*>(smem + NS * STAGE + 1024)[mloc] : ep.row_idx[m]);
+        const uint32_t e0 = (uint32_t)morig * (uint32_t)ep.Dtrue + (uint32_t)nbase;
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+          const int c = lane + 64 * u;
+          if (c < N) {
+            float x = sC[rr * SCW + c];
+            if (ep.drop.thresh) x = nr_keep(ep.drop.key, e0 + c, ep.drop.thresh) ? x * ep.drop.scale : 0.f;
+            if (det) runq[u] += nr_to_fix(x); else run[u] += x;
+          }
+        }
+      }
+      flush();
+    }
+    return;
+  }
   // epilogue: 32 rows at a time through the fp32 LDS tile (pass p = rows 32p..32p+31 = wave row wm = p>>1, tiles 2(p&1), +1)
 #pragma unroll 1
   for (int pass = 0; pass < 2 * WM; ++pass) {
@@ -2198,6 +2271,99 @@ int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* w
   return NR_OK;
 }
 
+// Live rows grouped by token id (counting sort on the device).
+namespace {
+__global__ __launch_bounds__(256) void id_hist_kernel(const int32_t* __restrict__ count, const int32_t* __restrict__ ids, int V,
+                                                      int32_t* __restrict__ hist) {
+  const int n = *count;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int id = ids[i];
+    if (id >= 0 && id < V) atomicAdd(hist + id, 1);
+  }
+}
+// exclusive scan of hist[0 .. V) in place, by one workgroup (V is a vocabulary size: tens of thousands).  in_lds: the
+// whole histogram is staged in LDS by coalesced, independent loads (the strided per-thread runs over global memory were a
+// chain of dependent-latency loads: 30 us of the sort's 80)
+__global__ __launch_bounds__(1024) void id_scan_kernel(int32_t* __restrict__ hist, int V, int in_lds) {
+  __shared__ int sSum[1024];
+  extern __shared__ __attribute__((aligned(16))) int sH[];
+  const int tid = threadIdx.x, per = (V + 1023) / 1024, v0 = tid * per, v1 = min(V, v0 + per);
+  if (in_lds) {
+    for (int base = 0; base < V; base += 8 * 1024) {
+      int x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = base + u * 1024 + tid;
+        x[u] = v < V ? hist[v] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = base + u * 1024 + tid;
+        if (v < V) sH[v] = x[u];
+      }
+    }
+    __syncthreads();
+  }
+  int c = 0;
+  for (int v = v0; v < v1; ++v) c += in_lds ? sH[v] : hist[v];
+  sSum[tid] = c;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int x = tid >= o ? sSum[tid - o] : 0;
+    __syncthreads();
+    sSum[tid] += x;
+    __syncthreads();
+  }
+  int run = sSum[tid] - c;
+  if (in_lds) {
+    for (int v = v0; v < v1; ++v) {
+      const int h = sH[v];
+      sH[v] = run;
+      run += h;
+    }
+    __syncthreads();
+    for (int v = tid; v < V; v += 1024) hist[v] = sH[v];
+  } else {
+    for (int v = v0; v < v1; ++v) {
+      const int h = hist[v];
+      hist[v] = run;
+      run += h;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void id_scatter_kernel(const int32_t* __restrict__ count, const int32_t* __restrict__ rows,
+                                                         const int32_t* __restrict__ ids, int V, int32_t* __restrict__ cursor,
+                                                         int32_t* __restrict__ rows_out, int32_t* __restrict__ ids_out) {
+  const int n = *count;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int id = ids[i];
+    if (id >= 0 && id < V) {
+      const int pos = atomicAdd(cursor + id, 1);
+      rows_out[pos] = rows[i];
+      ids_out[pos] = id;
+    }
+  }
+}
+}  // namespace
+
+int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const int32_t* ids, int Mmax, int table_rows, int32_t* hist,
+                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream) {
+  NR_CHECK_ARG(count && rows && ids && hist && rows_out && ids_out && Mmax > 0 && table_rows > 0, "sort_rows_by_id: bad arguments");
+  NrProfScope ps(stream, "sort_rows_by_id[Mmax=%d,V=%d]", Mmax, table_rows);
+  NR_CHECK_HIP(hipMemsetAsync(hist, 0, (size_t)table_rows * sizeof(int32_t), stream));
+  int grid = (Mmax + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(id_hist_kernel, dim3(grid), dim3(256), 0, stream, count, ids, table_rows, hist);
+  const int in_lds = table_rows <= 36 * 1024 ? 1 : 0;
+  if (in_lds) {
+    NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(id_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 1024 * 4));
+  }
+  hipLaunchKernelGGL(id_scan_kernel, dim3(1), dim3(1024), in_lds ? (size_t)((table_rows + 3) / 4) * 16 : 0, stream, hist, table_rows, in_lds);
+  hipLaunchKernelGGL(id_scatter_kernel, dim3(grid), dim3(256), 0, stream, count, rows, ids, table_rows, hist, rows_out, ids_out);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
 // Forward flavour: ws int32 [3*M + n + 4]; ws[2] = 1 when row 0 of the (bf16) table is not all zero -> every row live;
 // ws[4 + 3M + i] = bit mask of sequence i (L <= 32): bit t set = token t is live.
 int nr_launch_compact_rows_fwd(const int32_t* ids, int M, int n, int L, const void* table_row0, int cols, int32_t* ws,
@@ -2282,30 +2448,36 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
     // with row compaction only the live rows (count on the device) are multiplied: M is then an upper bound
     // "_live": rows compacted on the device; "_needed": row tiles of unneeded sequences are skipped (M is an upper bound in both)
     const bool tile_skip = (epi == EPI_STORE || epi == EPI_STORE_TANH) && ep.seq_nz != nullptr && ep.row_count == nullptr;
-    NrProfScope ps(stream, ep.row_count ? "gemm_nt_dma_live[bf16,epi=%d,Mmax=%d,N=%d,K=%d]"
-                                        : (tile_skip ? "gemm_nt_dma_needed[bf16,epi=%d,Mmax=%d,N=%d,K=%d]" : "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d]"),
-                   epi, M, N, K);
     // skinny K, bf16 out: weights-in-registers kernels (see gemm_nt_wreg_kernel); shapes with an instantiation:
     //   QKV projection    STORE       K in (288, 320], N >= 320        5 column tiles per wave, 16-row steps
     //   pooling fc1       STORE_TANH  K in (384, 416], N <= 256        2 column tiles per wave, 32-row steps
     //   pooling dX        POOLBWD     K in (192, 224], N <= 512        4 column tiles per wave, 32-row steps
+    // ("_needed" there: only 32-row blocks that touch a flagged sequence are computed)
     if (nr_opt(NR_OPT_NT_WREG) && ep.out_dtype == NR_BF16 && N % 8 == 0 && ep.ldc % 8 == 0 && M >= 64 && ldb >= kr32 &&
         (ep.row_count == nullptr || (((uintptr_t)ep.row_idx & 15) == 0 && M % 4 == 0))) {
       const bool flags = ep.seq_nz != nullptr && ep.row_count == nullptr && ep.L >= 16;
+      const char* lbl = ep.row_count ? "gemm_nt_wreg_live[bf16,epi=%d,Mmax=%d,N=%d,K=%d]"
+                                     : (ep.seq_nz ? "gemm_nt_wreg_needed[bf16,epi=%d,Mmax=%d,N=%d,K=%d]" : "gemm_nt_wreg[bf16,epi=%d,M=%d,N=%d,K=%d]");
       if (epi == EPI_STORE && !tile_skip && K > 288 && K <= 320 && N >= 320) {
+        NrProfScope ps(stream, lbl, epi, M, N, K);
         return ep.row_count ? launch_nt_wreg_m<EPI_STORE, 5, 10, 1, WREG_COMPACT>(A, B, ldb, M, N, K, ep, stream)
                             : launch_nt_wreg_m<EPI_STORE, 5, 10, 1, WREG_DENSE>(A, B, ldb, M, N, K, ep, stream);
       }
       if (epi == EPI_STORE_TANH && ep.row_count == nullptr && K > 384 && K <= 416 && N <= 256 && (!tile_skip || flags)) {
+        NrProfScope ps(stream, lbl, epi, M, N, K);
         return tile_skip ? launch_nt_wreg_m<EPI_STORE_TANH, 2, 13, 2, WREG_LIST>(A, B, ldb, M, N, K, ep, stream)
                          : launch_nt_wreg_m<EPI_STORE_TANH, 2, 13, 2, WREG_DENSE>(A, B, ldb, M, N, K, ep, stream);
       }
       if (epi == EPI_POOLBWD && ep.row_count == nullptr && K > 192 && K <= 224 && N <= 512 && ep.L >= 16 && ep.ldg % 4 == 0 &&
           (((uintptr_t)ep.G | (uintptr_t)ep.rowscale) & 15) == 0 && M % 4 == 0 && (ep.seq_nz == nullptr || flags)) {
+        NrProfScope ps(stream, lbl, epi, M, N, K);
         return ep.seq_nz ? launch_nt_wreg_m<EPI_POOLBWD, 4, 7, 2, WREG_LIST>(A, B, ldb, M, N, K, ep, stream)
                          : launch_nt_wreg_m<EPI_POOLBWD, 4, 7, 2, WREG_DENSE>(A, B, ldb, M, N, K, ep, stream);
       }
     }
+    NrProfScope ps(stream, ep.row_count ? "gemm_nt_dma_live[bf16,epi=%d,Mmax=%d,N=%d,K=%d]"
+                                        : (tile_skip ? "gemm_nt_dma_needed[bf16,epi=%d,Mmax=%d,N=%d,K=%d]" : "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d]"),
+                   epi, M, N, K);
     const int c13 = ((N + 207) / 208) * 13, c20 = ((N + 319) / 320) * 20;   // fewer padded column tiles wins
     if (c13 < c20) return launch_nt_dma_e<13>(A, B, ldb, M, N, K, epi, ep, stream);
     return launch_nt_dma_e<20>(A, B, ldb, M, N, K, epi, ep, stream);
@@ -2331,24 +2503,43 @@ __global__ __launch_bounds__(1024) void live_slabs_kernel(const int32_t* __restr
   extern __shared__ __attribute__((aligned(16))) unsigned char sFlag[];   // in_lds: the n sequence flags as bytes
   const int tid = threadIdx.x;
   if (in_lds) {
-    // one coalesced sweep with independent loads; the per-slab lookups below (2-3 flags per slab, a dependent chain of
-    // ~26 slabs per thread) then hit LDS instead of paying a global-memory latency each
-    for (int t = tid; t < n; t += 1024) sFlag[t] = title_nz[t] != 0 ? 1 : 0;
+    // one coalesced sweep with independent loads (8 in flight per thread); the per-slab lookups below (2-3 flags per slab,
+    // a dependent chain of ~26 slabs per thread) then hit LDS instead of paying a global-memory latency each
+    for (int base = 0; base < n; base += 8 * 1024) {
+      int v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = base + u * 1024 + tid;
+        v[u] = t < n ? title_nz[t] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = base + u * 1024 + tid;
+        if (t < n) sFlag[t] = v[u] != 0 ? 1 : 0;
+      }
+    }
     __syncthreads();
   }
   const int per = (nslab + 1023) / 1024, s0 = tid * per, s1 = min(nslab, s0 + per);
-  auto live = [&](int s) {
-    const int t0 = (32 * s) / L, t1 = min(n - 1, (32 * s + 31) / L);
-    bool lv = false;
-    if (in_lds) {
-      for (int t = t0; t <= t1; ++t) lv |= sFlag[t] != 0;
-    } else {
-      for (int t = t0; t <= t1; ++t) lv |= title_nz[t] != 0;
+  // sequence of row 32 s and its offset inside it are carried along the thread's run of slabs (one integer division per
+  // thread: two per slab, ~40 instructions each, were most of this kernel's 38 us)
+  const int tq = s0 < nslab ? (32 * s0) / L : 0, rq = 32 * s0 - tq * L;
+  auto flag = [&](int t) { return in_lds ? (int)sFlag[t] : (title_nz[t] != 0 ? 1 : 0); };
+  auto walk = [&](auto&& emit) {
+    int t = tq, rem = rq;
+    for (int s = s0; s < s1; ++s) {
+      int lv = flag(min(t, n - 1)), e = rem + 31, te = t;
+      while (e >= L) {                              // further sequences the slab's 32 rows reach into
+        e -= L; ++te;
+        if (te < n) lv |= flag(te);
+      }
+      emit(s, lv != 0);
+      rem += 32;
+      while (rem >= L) { rem -= L; ++t; }
     }
-    return lv;
   };
   int c = 0;
-  for (int s = s0; s < s1; ++s) c += live(s) ? 1 : 0;
+  walk([&](int, bool lv) { c += lv ? 1 : 0; });
   sCnt[tid] = c;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {                    // inclusive Hillis-Steele scan
@@ -2358,8 +2549,7 @@ __global__ __launch_bounds__(1024) void live_slabs_kernel(const int32_t* __restr
     __syncthreads();
   }
   int pos = sCnt[tid] - c;
-  for (int s = s0; s < s1; ++s)
-    if (live(s)) list[pos++] = s;
+  walk([&](int s, bool lv) { if (lv) list[pos++] = s; });
   if (tid == 1023) *count = sCnt[1023];
 }
 }  // namespace
@@ -2468,20 +2658,29 @@ __global__ __launch_bounds__(256) void needed_list_kernel(const int32_t* __restr
   }
 }
 // one workgroup per unneeded sequence: its rows (chunks16 16-byte pieces) become zeros
-__global__ __launch_bounds__(256) void zero_unneeded_kernel(const int32_t* __restrict__ flags, uint4* __restrict__ y, int chunks16) {
+// margin >= 0: only the unneeded sequences within `margin` sequences of a needed one (rows a 32-row slab of a
+// weight-gradient GEMM can reach next to live rows: their zero upstream gradient must meet finite numbers there)
+__global__ __launch_bounds__(256) void zero_unneeded_kernel(const int32_t* __restrict__ flags, int n, int margin, uint4* __restrict__ y,
+                                                            int chunks16) {
   const int seq = blockIdx.x;
   if (flags[seq] != 0) return;
+  if (margin >= 0) {
+    bool near = false;                                     // uniform
+    for (int t = max(0, seq - margin); t <= min(n - 1, seq + margin); ++t) near |= flags[t] != 0;
+    if (!near) return;
+  }
   uint4* p = y + (size_t)seq * chunks16;
   for (int c = threadIdx.x; c < chunks16; c += 256) p[c] = make_uint4(0, 0, 0, 0);
 }
 }  // namespace
-// out: int32 [4 + n]: out[0] = count, out[4 ..] = the needed sequences; y rows of the others are zero-filled (row_bytes % 16 == 0)
-int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream) {
+// out: int32 [4 + n]: out[0] = count, out[4 ..] = the needed sequences; y rows of the others are zero-filled (row_bytes % 16 == 0);
+// fill_margin >= 0: only of those within fill_margin sequences of a needed one
+int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream, int fill_margin) {
   NR_CHECK_ARG(flags != nullptr && out != nullptr && y != nullptr && seq_bytes % 16 == 0 && (((uintptr_t)y) & 15) == 0, "needed_list: bad arguments");
   NR_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream));
   NrProfScope ps(stream, "needed_list[n=%d]", n);
   hipLaunchKernelGGL(needed_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, flags, n, out, out + 4);
-  hipLaunchKernelGGL(zero_unneeded_kernel, dim3(n), dim3(256), 0, stream, flags, reinterpret_cast<uint4*>(y), (int)(seq_bytes / 16));
+  hipLaunchKernelGGL(zero_unneeded_kernel, dim3(n), dim3(256), 0, stream, flags, n, fill_margin, reinterpret_cast<uint4*>(y), (int)(seq_bytes / 16));
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
