@@ -151,10 +151,6 @@ typedef struct {
                          REQUIRED when nr_mhsa_fwd was given row_ws: on the bf16 title-level path the forward then leaves
                          the qkv rows of all-padding sequences unwritten (the attention kernels substitute the bias), and the
                          backward attention has to do the same.                                                   */
-  int needed_no_fill; /* nr_mhsa_fwd with seq_needed: nonzero = the caller never reads the y rows of sequences flagged 0 (it
-                         pools with the same flags): only those within 32 / L + 2 sequences of a needed one are zero-filled
-                         (a weight-gradient slab next to live rows may multiply them by a zero gradient: they must be
-                         finite), the others stay UNWRITTEN -- instead of a 0.3 GB store-only pass at the bench shape.  */
 } nr_mhsa_desc;
 
 /* qkv: [n*L, 3N] dtype (saved for backward); y: [n*L, N] dtype.

@@ -593,9 +593,7 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   const int32_t* fwd_list = nullptr;
   if (d->seq_needed != nullptr && tmask != nullptr && ((size_t)d->L * N * nr_elt_size(d->dtype)) % 16 == 0 && (((uintptr_t)y) & 15) == 0) {
     int32_t* lw = d->row_ws + W.seq;
-    if ((rc = nr_launch_needed_list(d->seq_needed, d->n, lw, y, (size_t)d->L * N * nr_elt_size(d->dtype), s,
-                                    d->needed_no_fill ? 32 / d->L + 2 : -1)))
-      return rc;
+    if ((rc = nr_launch_needed_list(d->seq_needed, d->n, lw, y, (size_t)d->L * N * nr_elt_size(d->dtype), s))) return rc;
     fwd_list = lw;
   }
   return nr_launch_attn(false, d->dtype, qkv, d->mask, y, nullptr, nullptr, d->n, d->L, d->heads, d->d_head,

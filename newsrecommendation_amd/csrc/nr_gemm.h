@@ -73,7 +73,7 @@ int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_
 int nr_launch_title_flags(const void* dy, int n, int L, int N, int32_t* title_nz, hipStream_t stream);
 int nr_launch_row_flags_f32(const float* g, int ld, int N, int n, int32_t* nz, hipStream_t stream);
 int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream);
-int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream, int fill_margin = -1);
+int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream);
 int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream);
 int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K,
                             int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream);

@@ -2658,29 +2658,20 @@ __global__ __launch_bounds__(256) void needed_list_kernel(const int32_t* __restr
   }
 }
 // one workgroup per unneeded sequence: its rows (chunks16 16-byte pieces) become zeros
-// margin >= 0: only the unneeded sequences within `margin` sequences of a needed one (rows a 32-row slab of a
-// weight-gradient GEMM can reach next to live rows: their zero upstream gradient must meet finite numbers there)
-__global__ __launch_bounds__(256) void zero_unneeded_kernel(const int32_t* __restrict__ flags, int n, int margin, uint4* __restrict__ y,
-                                                            int chunks16) {
+__global__ __launch_bounds__(256) void zero_unneeded_kernel(const int32_t* __restrict__ flags, uint4* __restrict__ y, int chunks16) {
   const int seq = blockIdx.x;
   if (flags[seq] != 0) return;
-  if (margin >= 0) {
-    bool near = false;                                     // uniform
-    for (int t = max(0, seq - margin); t <= min(n - 1, seq + margin); ++t) near |= flags[t] != 0;
-    if (!near) return;
-  }
   uint4* p = y + (size_t)seq * chunks16;
   for (int c = threadIdx.x; c < chunks16; c += 256) p[c] = make_uint4(0, 0, 0, 0);
 }
 }  // namespace
-// out: int32 [4 + n]: out[0] = count, out[4 ..] = the needed sequences; y rows of the others are zero-filled (row_bytes % 16 == 0);
-// fill_margin >= 0: only of those within fill_margin sequences of a needed one
-int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream, int fill_margin) {
+// out: int32 [4 + n]: out[0] = count, out[4 ..] = the needed sequences; y rows of the others are zero-filled (row_bytes % 16 == 0)
+int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream) {
   NR_CHECK_ARG(flags != nullptr && out != nullptr && y != nullptr && seq_bytes % 16 == 0 && (((uintptr_t)y) & 15) == 0, "needed_list: bad arguments");
   NR_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream));
   NrProfScope ps(stream, "needed_list[n=%d]", n);
   hipLaunchKernelGGL(needed_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, flags, n, out, out + 4);
-  hipLaunchKernelGGL(zero_unneeded_kernel, dim3(n), dim3(256), 0, stream, flags, n, fill_margin, reinterpret_cast<uint4*>(y), (int)(seq_bytes / 16));
+  hipLaunchKernelGGL(zero_unneeded_kernel, dim3(n), dim3(256), 0, stream, flags, reinterpret_cast<uint4*>(y), (int)(seq_bytes / 16));
   NR_CHECK_LAUNCH();
   return NR_OK;
 }

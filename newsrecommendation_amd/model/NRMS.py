@@ -29,9 +29,7 @@ class NewsEncoder(nn.Module):
         history slot): it is returned as zeros without being encoded."""
         p = self.drop_rate if self.training else 0.0
         needed = ops.needed_flags(needed)
-        # (the pooling below takes the same flags: the context rows of unneeded titles are never read, so they need no zero fill)
-        y = self.multi_head_self_attn.forward_gather(x, self.embedding_matrix.weight, mask=mask, p_in=p, p_out=p, needed=needed,
-                                                     needed_no_fill=True)
+        y = self.multi_head_self_attn.forward_gather(x, self.embedding_matrix.weight, mask=mask, p_in=p, p_out=p, needed=needed)
         return self.attn(y, mask, needed=needed)
 
 

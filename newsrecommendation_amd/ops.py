@@ -303,8 +303,7 @@ class MHSAFunction(Function):
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
                           x_rows=ptr(x_rows), ld_rows=Kp, seq_needed=ptr(cfg.get("needed")),
-                          table_rows=cfg["table_shape"][0] if gather else 0,     # (sizes the id-sort scratch of the backward)
-                          needed_no_fill=int(bool(cfg.get("needed_no_fill"))))
+                          table_rows=cfg["table_shape"][0] if gather else 0)     # (sizes the id-sort scratch of the backward)
         # scratch for the device-side compaction of non-padding rows (forward: live rows, their ids, padding rows;
         # backward: live slabs, sequence list) -- sized by the library
         row_ws = _ws(_lib.lib().nr_mhsa_workspace_bytes(C.byref(d)), dev) if keep_rows and code == _lib.NR_BF16 else None
@@ -396,15 +395,13 @@ def needed_flags(needed):
 
 
 def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int, code: int, mask=None, ids=None, table=None, p_in=0.0, p_out=0.0, flat=None,
-         needed=None, needed_no_fill=False):
+         needed=None):
     """Dense: x [n, L, d_model] (compute dtype).  Gather: ids int32 [n, L] + fp32 `table` parameter.
     flat: {"w": [3N, d_model], "b": [3N], "gw", "gb"} views of a flat parameter / gradient bucket (parallel.FlatBucket).
     needed: optional [n] int32 flags (needed_flags): sequences with flag 0 reach the loss through a factor 0 only; their
-    output rows are exact zeros and are not computed (their gradient is zero, so nothing flows back either).
-    needed_no_fill: those rows are not even zero-filled -- for callers that never read them (pooling with the same flags)."""
+    output rows are exact zeros and are not computed (their gradient is zero, so nothing flows back either)."""
     cfg = dict(code=code, heads=heads, p_in=float(p_in), p_out=float(p_out),
-               seed_in=draw_seed() if p_in > 0 else 0, seed_out=draw_seed() if p_out > 0 else 0, needed=needed,
-               needed_no_fill=bool(needed_no_fill) and needed is not None)
+               seed_in=draw_seed() if p_in > 0 else 0, seed_out=draw_seed() if p_out > 0 else 0, needed=needed)
     if flat is not None:
         cfg["flat"] = flat
     if ids is not None:
