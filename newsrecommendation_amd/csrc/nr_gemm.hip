@@ -1080,7 +1080,8 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
                      (((uintptr_t)ep.G & 15) == 0) && (((uintptr_t)ep.rowscale & 15) == 0) && M >= 4;
   const int t0 = (EPI == EPI_POOLBWD) ? m0 / max(ep.L, 1) : 0;
   // STORE / STORE_TANH: the bias of this column chunk, same idea (one DMA piece)
-  const bool b_lds = (EPI == EPI_STORE || EPI == EPI_STORE_TANH) && PK && ep.bias != nullptr && (nbase % 4 == 0) && N >= 4 &&
+  // (one piece holds 256 floats: the 320-column chunk reads its bias from global memory -- found by tests/test_gpu_gemm_wreg.py)
+  const bool b_lds = (EPI == EPI_STORE || EPI == EPI_STORE_TANH) && PK && WBN <= 256 && ep.bias != nullptr && (nbase % 4 == 0) && N >= 4 &&
                      (((uintptr_t)ep.bias & 15) == 0);
   if (b_lds && wid == NW - 1) dma16(ep.bias + nbase + min(4 * lane, ((N - 4) / 4) * 4), lds0 + NS * STAGE);
   // compacted STORE: the original row numbers of this tile (output rows are scattered back)
