@@ -142,9 +142,11 @@ typedef struct {
   const void* proj_table; /* nr_mhsa_fwd only, optional [V, 3N] dtype = table . W_qkv^T + b_qkv (one nr_gemm_nt over the table):
                          eval mode (p_in == 0, bf16 gather source, qkv == NULL, no backward) gathers the projections of a token
                          from here instead of projecting every occurrence -- same values, ~V/(n*L) of the GEMM work */
-  const int32_t* seq_needed; /* nr_mhsa_fwd only, optional [n]: 0 = the caller will not use this sequence's output (it reaches the
+  const int32_t* seq_needed; /* optional [n]: 0 = the caller will not use this sequence's output (it reaches the
                          loss through a factor 0, e.g. a masked history slot, src/model/NRMS.py:59-60, model_utils.py:28,51): its y rows
-                         are written as exact zeros without being computed.  NULL: every sequence is computed.              */
+                         are written as exact zeros without being computed.  NULL: every sequence is computed.  With row_ws the
+                         forward also leaves the x_rows of all-padding sequences farther than 32 / L + 2 sequences from every
+                         needed one unwritten (nothing reads them): pass the SAME flags to nr_mhsa_bwd.                      */
   const int32_t* seq_nz; /* nr_mhsa_bwd only, optional [n]: 0 = the upstream gradient dy of this sequence is exactly zero (the flags
                          nr_additive_pool_bwd leaves in its workspace, see nr_pool_seq_flags); NULL: the library scans dy itself */
   int row_ws_ready;   /* nr_mhsa_bwd only: nonzero = row_ws still holds what nr_mhsa_fwd wrote for these ids (reused as is).

@@ -568,13 +568,20 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   if (d->x_rows != nullptr && d->src_kind == NR_SRC_GATHER) {
     // gather + dropout once into x_rows (kept for the backward), then a plain dense projection GEMM
     NR_CHECK_ARG(d->ld_rows >= Kp && d->ld_rows % nr_chunk(d->dtype) == 0, "mhsa_fwd: ld_rows=%d must cover %d", d->ld_rows, Kp);
-    if ((rc = nr_launch_rows_materialize(d->dtype, A, d->x_rows, d->ld_rows, M, Kp, s))) return rc;
+    const bool compacting = d->row_ws != nullptr && d->dtype == NR_BF16 && M >= 4096 && (3 * N) % 8 == 0;
+    // Padding tokens (id 0) gather the zero row of the table: their projection is the bias.  Project the live rows
+    // only (compacted on the device) and write the bias into the others.  If table row 0 is not zero, the
+    // compaction keeps every row and nothing changes.
+    if (compacting && (rc = nr_launch_compact_rows_fwd(d->ids, M, d->n, d->L, d->x, d->d_model, d->row_ws, s))) return rc;
+    // under "needed" flags the rows of all-padding sequences no weight-gradient slab can reach are not even written
+    // (only where the backward contracts live slabs: a dense contraction would read every row)
+    const bool skip_far = compacting && d->seq_needed != nullptr && M % 32 == 0 && nr_gemm_tn_slabs_ok(3 * N, d->ld_rows, M, 3 * N, Kp) &&
+                          !nr_opt(NR_OPT_NO_SLABS);
+    if ((rc = nr_launch_rows_materialize(d->dtype, A, d->x_rows, d->ld_rows, M, Kp, s, skip_far ? d->seq_needed : nullptr, 32 / d->L + 2,
+                                         d->L, skip_far ? d->row_ws + 2 : nullptr)))
+      return rc;
     A = dense_rows(d->x_rows, d->ld_rows, d->d_model);
-    if (d->row_ws != nullptr && d->dtype == NR_BF16 && M >= 4096 && (3 * N) % 8 == 0) {
-      // Padding tokens (id 0) gather the zero row of the table: their projection is the bias.  Project the live rows
-      // only (compacted on the device) and write the bias into the others.  If table row 0 is not zero, the
-      // compaction keeps every row and nothing changes.
-      if ((rc = nr_launch_compact_rows_fwd(d->ids, M, d->n, d->L, d->x, d->d_model, d->row_ws, s))) return rc;
+    if (compacting) {
       ep.row_count = d->row_ws; ep.row_idx = d->row_ws + W.live_idx; ep.row_ids = d->row_ws + W.live_ids;
       // Sequences made of padding tokens only (empty history slots, ~45 % of the titles of a MIND-shaped batch): the
       // attention kernels take their Q|K|V from the bias themselves (per-sequence live mask == 0), so those qkv rows are
@@ -646,6 +653,12 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
       if ((rc = nr_launch_seq_list(slab_ws, tmask, d->n, d->L, seq_ws, s))) return rc;
     }
   }
+  // x_rows written under "needed" flags (nr_mhsa_fwd: skip_far) are complete only where a live slab can reach: the slab
+  // path is then mandatory (a dense contraction would multiply unwritten rows by their zero gradient)
+  NR_CHECK_ARG(!(d->row_ws_ready && d->seq_needed != nullptr && d->row_ws != nullptr && d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER &&
+                 d->x_rows != nullptr && M >= 4096 && (3 * N) % 8 == 0 && M % 32 == 0 && nr_gemm_tn_slabs_ok(3 * N, d->ld_rows, M, 3 * N, Kp) &&
+                 !no_slabs) || slab_ws != nullptr,
+               "mhsa_bwd: x_rows were materialised under seq_needed: qkv / dqkv / dy must be 8-byte aligned so that the live-slab path runs");
   if ((rc = nr_launch_attn(true, d->dtype, qkv, d->mask, nullptr, dy, dqkv, d->n, d->L, d->heads, d->d_head,
                            nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr, seq_ws ? seq_ws + 4 : nullptr,
                            seq_ws)))

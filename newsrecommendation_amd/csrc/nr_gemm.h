@@ -54,8 +54,10 @@ struct EpiArgs {
 int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi,
                       const EpiArgs& ep, hipStream_t stream);
 // needed (optional, im2col rows): [M / Tlen] flags; titles farther than `margin` titles from every needed one are not written
+// (gather rows: + L tokens per sequence and keep_all = device flag "table row 0 is not zero": all-padding sequences far
+//  from every needed one are skipped)
 int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, int M, int K, hipStream_t stream,
-                               const int32_t* needed = nullptr, int margin = 0);
+                               const int32_t* needed = nullptr, int margin = 0, int L = 0, const int32_t* keep_all = nullptr);
 // ws: int32 [2*M + 4] -> ws[0] = number of rows with ids[m*stride] != 0, ws[4 ..] their row numbers, ws[4 + M ..] their ids
 int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* ws, hipStream_t stream);
 // live rows (count on the device, their row numbers and token ids) -> the same rows grouped by token id (counting sort:

@@ -2155,6 +2155,31 @@ __global__ __launch_bounds__(256) void im2col3_title_kernel(RowSrc A, T* __restr
   }
 }
 
+// Gathered rows, one workgroup per sequence of L tokens, under "needed" flags: an all-padding sequence (every id 0, table
+// row 0 zero: *keep_all == 0) has no live row for the projection to read, and if no needed sequence lies within `margin`
+// sequences no 32-row slab of the weight-gradient GEMM reaches it either -- its rows are not written.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_title_kernel(RowSrc A, T* __restrict__ out, int ldo, int M, int K, int L,
+                                                           const int32_t* __restrict__ needed, int n, int margin,
+                                                           const int32_t* __restrict__ keep_all) {
+  constexpr int CH = 16 / (int)sizeof(T);
+  const int cpr = K / CH, blk = blockIdx.x;
+  __shared__ int near;
+  if (threadIdx.x == 0) near = *keep_all != 0 ? 1 : 0;
+  __syncthreads();
+  for (int t = max(0, blk - margin) + (int)threadIdx.x; t <= min(n - 1, blk + margin); t += 256)
+    if (needed[t] != 0) near = 1;                        // benign race: every writer stores 1
+  for (int t = threadIdx.x; t < L; t += 256)
+    if (blk * L + t < M && A.ids[(size_t)(blk * L + t) * A.ids_stride] != 0) near = 1;
+  __syncthreads();
+  if (!near) return;
+  for (int u = threadIdx.x; u < L * cpr; u += 256) {
+    const int t = u / cpr, k = (u - t * cpr) * CH, m = blk * L + t;
+    if (m >= M) break;
+    *reinterpret_cast<uint4*>(out + (size_t)m * ldo + k) = load_rows_chunk<T, ROWS_GATHER>(A, m, k, M, K);
+  }
+}
+
 // Row compaction for the table-gradient GEMM: rows with token id 0 add nothing (padding_idx), and in a MIND-shaped
 // batch they are ~70 % of all rows (zero-padded title tails, empty history slots).  One pass, no host round trip:
 // 256 rows per workgroup, order kept inside a workgroup, workgroups append through one atomic counter.
@@ -2393,9 +2418,19 @@ int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_
 }
 
 int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, int M, int K, hipStream_t stream, const int32_t* needed,
-                               int margin) {
+                               int margin, int L, const int32_t* keep_all) {
   const int ch = nr_chunk(dtype);
   NR_CHECK_ARG((A.kind == ROWS_GATHER || A.kind == ROWS_IM2COL3) && K % ch == 0 && ldo % ch == 0 && ldo >= K, "rows_materialize: bad arguments");
+  if (needed != nullptr && A.kind == ROWS_GATHER && L > 0 && M % L == 0 && keep_all != nullptr) {
+    NrProfScope ps(stream, "rows_materialize_needed[%s,Mmax=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", M, K);
+    const int n = M / L;
+    if (dtype == NR_BF16)
+      hipLaunchKernelGGL(gather_title_kernel<bf16_t>, dim3(n), dim3(256), 0, stream, A, (bf16_t*)out, ldo, M, K, L, needed, n, margin, keep_all);
+    else
+      hipLaunchKernelGGL(gather_title_kernel<float>, dim3(n), dim3(256), 0, stream, A, (float*)out, ldo, M, K, L, needed, n, margin, keep_all);
+    NR_CHECK_LAUNCH();
+    return NR_OK;
+  }
   if (needed != nullptr && A.kind == ROWS_IM2COL3 && K == 3 * A.ld && M % A.Tlen == 0) {
     NrProfScope ps(stream, "rows_materialize_needed[%s,Mmax=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", M, K);
     const int n = M / A.Tlen;

@@ -344,7 +344,8 @@ class MHSAFunction(Function):
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
                           x_rows=ptr(x_rows), ld_rows=x_rows.shape[1] if x_rows is not None else 0,
-                          table_rows=cfg["table_shape"][0] if gather else 0, seq_nz=seq_nz, row_ws_ready=int(ws_ready))
+                          table_rows=cfg["table_shape"][0] if gather else 0, seq_nz=seq_nz, row_ws_ready=int(ws_ready),
+                          seq_needed=ptr(cfg.get("needed")))     # (the forward may have left far all-padding x_rows unwritten)
         if need_x:
             w_t = pack(wcat, code, transpose=True)                     # [d_model, 3N]
             if gather:
