@@ -201,10 +201,12 @@ typedef struct {
   uint32_t seed_in;
   const void* w_pack; /* [N, 3*Dp] dtype (nr_pack_conv_w) */
   const float* bias;  /* [N] */
-  void* x_rows;       /* optional scratch [n*T, ld_rows] dtype: the forward stores the im2col rows (gather + dropout, three
-                         taps side by side) here once and runs a dense GEMM on them; a backward given the same buffer
-                         reuses them.  NULL: the operand is gathered on the fly inside the GEMMs.               */
-  int ld_rows;        /* >= 3*Dp */
+  void* x_rows;       /* optional scratch [n*(T+1)+1, Dp] dtype: the forward stores the token rows (gather + dropout) here
+                         once -- token t of title i at row i*(T+1)+1+t, zero rows in between -- so that the im2col row of
+                         a token is 3*Dp CONTIGUOUS elements starting one row above it, and runs the LDS-DMA GEMM on those
+                         overlapping rows (no 3x im2col copy); a backward given the same buffer reuses them.
+                         NULL: the operand is gathered on the fly inside the GEMMs.                                   */
+  int ld_rows;        /* == Dp */
   int32_t* bwd_ws;    /* optional backward scratch of nr_conv_workspace_bytes(d) bytes (bf16, with x_rows): nr_conv1d_k3_bwd flags the
                          titles whose upstream gradient dy is not all zero and contracts only the 32-row slabs that touch
                          one (masked history slots have an exactly zero dy).  NULL: every row is contracted.          */

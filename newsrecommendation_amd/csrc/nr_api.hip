@@ -758,15 +758,15 @@ int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   const int M = d->n * d->T, K = 3 * d->Dp;
   if (d->x_rows != nullptr) {
-    // im2col rows (gather + dropout hashed once) -> dense operand for the LDS-DMA GEMM
-    NR_CHECK_ARG(d->ld_rows >= K && d->ld_rows % nr_chunk(d->dtype) == 0, "conv1d_fwd: ld_rows=%d must cover %d", d->ld_rows, K);
+    // token rows (gather + dropout hashed once) with a zero row between titles: the im2col row of a token is then 3 * Dp
+    // CONTIGUOUS elements of that buffer -- a dense operand with overlapping rows for the LDS-DMA GEMM, no 3x copy
+    NR_CHECK_ARG(d->ld_rows == d->Dp, "conv1d_fwd: x_rows is [n * (T + 1) + 1, Dp] (ld_rows=%d, Dp=%d)", d->ld_rows, d->Dp);
     // with "needed" flags only the titles near a needed one are materialised: a 256-row GEMM tile / a 32-row slab spans
     // at most 256 / T + 2 titles
     // (only on shapes whose backward reads x_rows through the live-slab list -- a dense contraction would read every row)
-    if ((rc = nr_launch_rows_materialize(d->dtype, A, d->x_rows, d->ld_rows, M, K, s, conv_slab_shape(d) ? d->seq_needed : nullptr,
-                                         256 / d->T + 2)))
-      return rc;
-    A = dense_rows(d->x_rows, d->ld_rows, K);
+    if ((rc = nr_launch_conv_rows(d->dtype, A, d->x_rows, d->n, s, conv_slab_shape(d) ? d->seq_needed : nullptr, 256 / d->T + 2))) return rc;
+    A = dense_rows(d->x_rows, d->Dp, K);
+    A.gap = d->T;
   }
   return nr_launch_gemm_nt(d->dtype, A, d->w_pack, K, M, d->N, K, EPI_STORE, ep, s);
 }
@@ -786,8 +786,9 @@ int nr_conv1d_k3_bwd(const nr_conv_desc* d, const void* dy, float* dw_pack, floa
   det.add(db, (size_t)d->N);
   if ((rc = det.begin(true, false))) return rc;
   if (d->x_rows != nullptr) {   // the rows the forward stored
-    NR_CHECK_ARG(d->ld_rows >= 3 * d->Dp, "conv1d_bwd: ld_rows=%d must cover %d", d->ld_rows, 3 * d->Dp);
-    A = dense_rows(d->x_rows, d->ld_rows, 3 * d->Dp);
+    NR_CHECK_ARG(d->ld_rows == d->Dp, "conv1d_bwd: x_rows is [n * (T + 1) + 1, Dp] (ld_rows=%d, Dp=%d)", d->ld_rows, d->Dp);
+    A = dense_rows(d->x_rows, d->Dp, 3 * d->Dp);
+    A.gap = d->T;
     // titles with an exactly zero upstream gradient (masked history slots) add nothing to dW / db: live slabs only
     const bool no_slabs = nr_opt(NR_OPT_NO_SLABS) != 0;
     const int M = d->n * d->T;
@@ -803,8 +804,8 @@ int nr_conv1d_k3_bwd(const nr_conv_desc* d, const void* dy, float* dw_pack, floa
         return rc;
       }
       if ((rc = nr_launch_live_slabs(d->bwd_ws, d->n, d->T, s))) return rc;
-      return nr_launch_gemm_tn_slabs(dy, d->N, d->x_rows, d->ld_rows, dw_pack, 3 * d->Dp, db, M, d->N, 3 * d->Dp, d->N, 3 * d->Dp,
-                                     d->bwd_ws + d->n + 4, d->bwd_ws + d->n, s);
+      return nr_launch_gemm_tn_slabs(dy, d->N, d->x_rows, d->Dp, dw_pack, 3 * d->Dp, db, M, d->N, 3 * d->Dp, d->N, 3 * d->Dp,
+                                     d->bwd_ws + d->n + 4, d->bwd_ws + d->n, s, d->T);
     }
   }
   return nr_launch_gemm_tn(d->dtype, dy, d->N, A, dw_pack, 3 * d->Dp, db, d->n * d->T, d->N, 3 * d->Dp, d->N, 3 * d->Dp,

@@ -18,6 +18,9 @@ struct RowSrc {
   int Tlen;            // im2col3: tokens per block
   int Dtrue;           // dropout: elements per logical row (index = row*Dtrue + col, applied for col < Dtrue)
   DropCfg drop;
+  int gap;             // dense, > 0: logical row m starts at buffer row m + m / gap (one extra row after every `gap` rows) and may
+                       // run on into the following buffer rows (K > ld): the k = 3 convolution's token rows with a zero row
+                       // between titles (nr_launch_conv_rows)
 };
 
 enum {
@@ -48,11 +51,17 @@ struct EpiArgs {
                              // tiles made of such sequences only are skipped (their rows stay unwritten)
   void* rows_out;         // optional: the staged A rows (after gather / dropout), dtype, [M, ld_rows_out]
   int ld_rows_out;
+  int a_gap;              // LDS-DMA kernel: RowSrc::gap of the A operand (set by the launcher)
 };
 
 // C-level launchers (enqueue only).  dtype selects T.
 int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M, int N, int K, int epi,
                       const EpiArgs& ep, hipStream_t stream);
+// The k = 3 convolution's operand without an im2col buffer: out = [n * (T + 1) + 1, Dp] token rows (gather + dropout once),
+// title blk's token t at row blk * (T + 1) + 1 + t, zero rows in between.  The im2col row of token m = (blk, t) is then
+// the 3 * Dp CONTIGUOUS elements starting at row m + blk = m + m / T: a dense operand with ld = Dp, K = 3 Dp, gap = T.
+// needed (optional [n]) / margin: titles farther than margin titles from every needed one are not written.
+int nr_launch_conv_rows(int dtype, const RowSrc& A, void* out, int n, hipStream_t stream, const int32_t* needed = nullptr, int margin = 0);
 // needed (optional, im2col rows): [M / Tlen] flags; titles farther than `margin` titles from every needed one are not written
 // (gather rows: + L tokens per sequence and keep_all = device flag "table row 0 is not zero": all-padding sequences far
 //  from every needed one are skipped)
@@ -78,7 +87,7 @@ int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream);
 int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream);
 int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream);
 int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K,
-                            int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream);
+                            int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream, int xgap = 0);
 bool nr_gemm_tn_slabs_ok(int ldc, int ldx, int M, int N, int K);
 int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db,
                       int M, int N, int K, int Nstore, int Kstore, hipStream_t stream);

@@ -74,7 +74,7 @@ __device__ __forceinline__ uint4 load_rows_chunk(const RowSrc& s, int m, int k, 
   uint32_t eidx;
   int col = k;
   if (KIND == ROWS_DENSE) {
-    p = (const T*)s.base + (size_t)m * s.ld + k;
+    p = (const T*)s.base + (size_t)(s.gap > 0 ? m + m / s.gap : m) * s.ld + k;
     eidx = (uint32_t)m * (uint32_t)s.Dtrue + (uint32_t)k;
   } else if (KIND == ROWS_GATHER) {
     const int id = s.ids[(size_t)m * s.ids_stride];
@@ -112,7 +112,7 @@ __device__ __forceinline__ RowCtx<T> make_row_ctx(const RowSrc& s, int m, int M)
   c.p = nullptr; c.e0 = 0; c.t = 0;
   if (!c.valid) return c;
   if (KIND == ROWS_DENSE) {
-    c.p = (const T*)s.base + (size_t)m * s.ld;
+    c.p = (const T*)s.base + (size_t)(s.gap > 0 ? m + m / s.gap : m) * s.ld;
     c.e0 = (uint32_t)m * (uint32_t)s.Dtrue;
   } else if (KIND == ROWS_GATHER) {
     const int id = s.ids[(size_t)m * s.ids_stride];
@@ -1037,6 +1037,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
     if (p < DBM / 16) {
       int arow = min(m0 + 16 * p + prow, M - 1);
       if (compact) arow = ep.row_idx[arow];        // compacted row -> row of A
+      if (ep.a_gap > 0) arow += arow / ep.a_gap;   // token rows with a zero row between titles (RowSrc::gap)
       src[t] = A + (size_t)arow * lda + c8;
       isA[t] = true;
     } else {
@@ -1831,7 +1832,7 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
                                                             int ldx, float* __restrict__ dW, int ldw, float* __restrict__ db,
                                                             int M, int N, int K, int Nstore, int Kstore, int tilesK, int ntile,
                                                             int nsplit, int rps, const int32_t* __restrict__ slab_list,
-                                                            const int32_t* __restrict__ slab_count) {
+                                                            const int32_t* __restrict__ slab_count, int xgap) {
   using G = Geo<WK, NI>;
   constexpr int TBN = G::TBN, TBK = G::TBK, NT = G::NT, NW = G::NW, CHA = G::CHA, CH = G::CH, SCW = G::SCW, PA = G::PA, NP = G::NP,
                 STAGE = G::STAGE;
@@ -1872,9 +1873,11 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
 
   const bf16_t* src[PB + 1];
   size_t adv[PB + 1];
+  int xrow[PB + 1];                                 // X pieces: the lane's row (xgap > 0: logical row m sits at X row m + m / xgap)
 #pragma unroll
   for (int t = 0; t < PB + 1; ++t) {
     const int p = pfirst + t;
+    xrow[t] = -1;
     if (p < PA) {
       const int P = 64 * p + lane, row = P / CHA, cpos = P - row * CHA;
       const int col = min(n0 + swz_a(row, cpos) * 8, N - 8);
@@ -1885,13 +1888,24 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
       const int col = min(k0 + swz_b<WK>(row, cpos) * 8, K - 8);
       src[t] = X + (size_t)(mbeg + row) * ldx + col;
       adv[t] = (size_t)TBM * ldx;
+      xrow[t] = mbeg + row;
     }
   }
+  const uint32_t ginv = xgap > 0 ? (uint32_t)((0x100000000ull + (uint32_t)xgap - 1) / (uint32_t)xgap) : 0u;   // ceil(2^32 / xgap)
   auto issue = [&](int stage, int kt) {
     const size_t sl = slabs ? (size_t)sSlab[kt] : (size_t)kt;
 #pragma unroll
     for (int t = 0; t < PB + 1; ++t)
-      if (t < PB || extra) dma16(src[t] + sl * adv[t], lds0 + stage * STAGE + (pfirst + t) * 1024);
+      if (t < PB || extra) {
+        size_t off = sl * adv[t];
+        if (xgap > 0 && xrow[t] >= 0) {
+          const uint32_t m = (uint32_t)sl * TBM + (uint32_t)xrow[t];
+          uint32_t q = __umulhi(m, ginv);            // m / xgap, exact after one correction for m < 2^31
+          if (q * (uint32_t)xgap > m) --q;
+          off += (size_t)q * ldx;
+        }
+        dma16(src[t] + off, lds0 + stage * STAGE + (pfirst + t) * 1024);
+      }
   };
   auto wait_stages = [&](int stages) {
     if (extra) {
@@ -1986,7 +2000,7 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
 
 template <int WK, int NI>
 int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
-             int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr) {
+             int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr, int xgap = 0) {
   using G = Geo<WK, NI>;
   const int tilesN = (N + G::TBN - 1) / G::TBN, tilesK = (K + G::TBK - 1) / G::TBK, ntile = tilesN * tilesK;
   // ONE round of resident workgroups (256 CUs x 1 or 2), splits a multiple of the 8 XCDs, >= 16 slabs per split.
@@ -2005,7 +2019,7 @@ int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM));
   if (slab_list != nullptr && (M / TBM + nsplit - 1) / nsplit > 1024) slab_list = nullptr;   // a split's list must fit its LDS stage
   hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::SMEM, stream, (const bf16_t*)dC, ldc, (const bf16_t*)X, ldx, dW, ldw, db, M, N,
-                     K, Nstore, Kstore, tilesK, ntile, nsplit, rps, slab_list, slab_list ? slab_count : nullptr);
+                     K, Nstore, Kstore, tilesK, ntile, nsplit, rps, slab_list, slab_list ? slab_count : nullptr, xgap);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -2017,16 +2031,16 @@ bool eligible(int ldc, int ldx, int M, int N, int K) {
   return !off && M % TBM == 0 && M >= 200000 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0 && ldc % 8 == 0 && ldx % 8 == 0;
 }
 int launch(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
-           int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr) {
+           int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr, int xgap = 0) {
   const int force = nr_opt(NR_OPT_TN3_WK);
   const int force_ni = nr_opt(NR_OPT_TN3_NI);
   const bool wide = force ? force == 4 : (K > 160 && ((K + 319) / 320) * 320 * 100 <= K * 115);
   if (wide) {
     const bool big = force_ni ? force_ni == 8 : N > 256;
-    if (big) return launch_t<4, 8>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count);
-    return launch_t<4, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count);
+    if (big) return launch_t<4, 8>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap);
+    return launch_t<4, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap);
   }
-  return launch_t<2, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count);
+  return launch_t<2, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap);
 }
 }  // namespace tn3
 
@@ -2152,6 +2166,31 @@ __global__ __launch_bounds__(256) void im2col3_title_kernel(RowSrc A, T* __restr
     else *reinterpret_cast<uint4*>(o + 2 * Dp) = zero;
     if (t > 0) *reinterpret_cast<uint4*>(o - ldo + 2 * Dp) = v;
     else *reinterpret_cast<uint4*>(o) = zero;
+  }
+}
+
+// Token rows of the k = 3 convolution (nr_launch_conv_rows): one workgroup per title writes its T gathered (+ dropped-out)
+// rows and BOTH zero rows around them (a neighbour that is skipped would not write the shared one).
+template <typename T>
+__global__ __launch_bounds__(256) void conv_rows_kernel(RowSrc A, T* __restrict__ out, int n, const int32_t* __restrict__ needed, int margin) {
+  constexpr int CH = 16 / (int)sizeof(T);
+  const int Dp = A.ld, cpr = Dp / CH, T_ = A.Tlen, blk = blockIdx.x;
+  if (needed != nullptr) {
+    __shared__ int near;
+    if (threadIdx.x == 0) near = 0;
+    __syncthreads();
+    for (int t = max(0, blk - margin) + (int)threadIdx.x; t <= min(n - 1, blk + margin); t += 256)
+      if (needed[t] != 0) near = 1;                      // benign race: every writer stores 1
+    __syncthreads();
+    if (!near) return;
+  }
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  T* o0 = out + (size_t)blk * (T_ + 1) * Dp;               // the zero row in front of this title
+  for (int u = threadIdx.x; u < (T_ + 2) * cpr; u += 256) {
+    const int r = u / cpr, d = (u - r * cpr) * CH;         // r = 0: leading zero row, 1..T: tokens, T+1: trailing zero row
+    uint4 v = zero;
+    if (r >= 1 && r <= T_) v = load_rows_chunk<T, ROWS_IM2COL3>(A, blk * T_ + r - 1, Dp + d, n * T_, 3 * Dp);   // centre tap = the token itself
+    *reinterpret_cast<uint4*>(o0 + (size_t)r * Dp + d) = v;
   }
 }
 
@@ -2417,6 +2456,16 @@ int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_
   return NR_OK;
 }
 
+int nr_launch_conv_rows(int dtype, const RowSrc& A, void* out, int n, hipStream_t stream, const int32_t* needed, int margin) {
+  NR_CHECK_ARG(A.kind == ROWS_IM2COL3 && out != nullptr && n > 0 && A.ld % nr_chunk(dtype) == 0, "conv_rows: bad arguments");
+  NrProfScope ps(stream, needed ? "conv_rows_needed[%s,n=%d,T=%d,Dp=%d]" : "conv_rows[%s,n=%d,T=%d,Dp=%d]", dtype == NR_BF16 ? "bf16" : "f32", n,
+                 A.Tlen, A.ld);
+  if (dtype == NR_BF16) hipLaunchKernelGGL(conv_rows_kernel<bf16_t>, dim3(n), dim3(256), 0, stream, A, (bf16_t*)out, n, needed, margin);
+  else hipLaunchKernelGGL(conv_rows_kernel<float>, dim3(n), dim3(256), 0, stream, A, (float*)out, n, needed, margin);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
 int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, int M, int K, hipStream_t stream, const int32_t* needed,
                                int margin, int L, const int32_t* keep_all) {
   const int ch = nr_chunk(dtype);
@@ -2479,7 +2528,10 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
   const int kr32 = (K + 31) / 32 * 32;
   const bool dense_bf16 = dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0 && ep.rows_out == nullptr;
   const int dma_min_k = nr_opt(NR_OPT_DMA_MIN_K);
-  if (dense_bf16 && !no_dma && K >= dma_min_k && ldb >= kr32 && A.ld >= K) {
+  if (dense_bf16 && !no_dma && K >= dma_min_k && ldb >= kr32 && (A.ld >= K || A.gap > 0)) {
+    EpiArgs epg = ep;
+    epg.a_gap = A.gap;
+    const EpiArgs& ep = epg;                       // (shadows the parameter: the kernels below see the operand's row gap)
     // B must be zero beyond K up to the next multiple of 32 (nr_cast_pad with such an ld guarantees it)
     // with row compaction only the live rows (count on the device) are multiplied: M is then an upper bound
     // "_live": rows compacted on the device; "_needed": row tiles of unneeded sequences are skipped (M is an upper bound in both)
@@ -2489,7 +2541,7 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
     //   pooling fc1       STORE_TANH  K in (384, 416], N <= 256        2 column tiles per wave, 32-row steps
     //   pooling dX        POOLBWD     K in (192, 224], N <= 512        4 column tiles per wave, 32-row steps
     // ("_needed" there: only 32-row blocks that touch a flagged sequence are computed)
-    if (nr_opt(NR_OPT_NT_WREG) && ep.out_dtype == NR_BF16 && N % 8 == 0 && ep.ldc % 8 == 0 && M >= 64 && ldb >= kr32 &&
+    if (nr_opt(NR_OPT_NT_WREG) && A.gap == 0 && ep.out_dtype == NR_BF16 && N % 8 == 0 && ep.ldc % 8 == 0 && M >= 64 && ldb >= kr32 &&
         (ep.row_count == nullptr || (((uintptr_t)ep.row_idx & 15) == 0 && M % 4 == 0))) {
       const bool flags = ep.seq_nz != nullptr && ep.row_count == nullptr && ep.L >= 16;
       const char* lbl = ep.row_count ? "gemm_nt_wreg_live[bf16,epi=%d,Mmax=%d,N=%d,K=%d]"
@@ -2518,7 +2570,7 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
     if (c13 < c20) return launch_nt_dma_e<13>(A, B, ldb, M, N, K, epi, ep, stream);
     return launch_nt_dma_e<20>(A, B, ldb, M, N, K, epi, ep, stream);
   }
-  if (dense_bf16 && !no_wide && N <= 208) {
+  if (dense_bf16 && !no_wide && N <= 208 && A.gap == 0) {
     NrProfScope ps(stream, "gemm_nt_wide[bf16,epi=%d,M=%d,N=%d,K=%d]", epi, M, N, K);
     return launch_nt_wide_e<13>(A, B, ldb, M, N, K, epi, ep, stream);
   }
@@ -2734,10 +2786,10 @@ int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream) {
 }
 
 int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K,
-                            int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream) {
+                            int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream, int xgap) {
   NR_CHECK_ARG(tn3::eligible(ldc, ldx, M, N, K), "gemm_tn_slabs: shape not eligible");
   NrProfScope ps(stream, "gemm_tn3_live[bf16,Mmax=%d,N=%d,K=%d]", M, N, K);
-  return tn3::launch(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count);
+  return tn3::launch(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap);
 }
 bool nr_gemm_tn_slabs_ok(int ldc, int ldx, int M, int N, int K) { return tn3::eligible(ldc, ldx, M, N, K); }
 
@@ -2752,10 +2804,12 @@ int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float
   if (!tn_v1 && dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0) {
     if (tn3::eligible(ldc, A.ld, M, N, K)) {
       NrProfScope ps(stream, "gemm_tn3[bf16,M=%d,N=%d,K=%d]", M, N, K);
-      return tn3::launch(dC, ldc, A.base, A.ld, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+      return tn3::launch(dC, ldc, A.base, A.ld, dW, ldw, db, M, N, K, Nstore, Kstore, stream, nullptr, nullptr, A.gap);
     }
-    NrProfScope ps(stream, "gemm_tn2[bf16,M=%d,N=%d,K=%d]", M, N, K);
-    return tn2::launch(dC, ldc, A.base, A.ld, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+    if (A.gap == 0) {                              // (gapped rows: the generic kernel below follows RowSrc::gap)
+      NrProfScope ps(stream, "gemm_tn2[bf16,M=%d,N=%d,K=%d]", M, N, K);
+      return tn2::launch(dC, ldc, A.base, A.ld, dW, ldw, db, M, N, K, Nstore, Kstore, stream);
+    }
   }
   NrProfScope ps(stream, "gemm_tn[%s,rows=%d,M=%d,N=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", A.kind, M, N, K);
   return dtype == NR_BF16 ? launch_tn_d<bf16_t>(dC, ldc, A, dW, ldw, db, M, N, K, Nstore, Kstore, stream)

@@ -646,11 +646,12 @@ class ConvFunction(Function):
         check(_lib.lib().nr_pack_conv_w(ptr(wc), N, D, ptr(w_p), Dp, code, _stream()), "nr_pack_conv_w")
         b_c = b.detach().float().contiguous()
         y = torch.empty(n, T, N, dtype=torch_dtype(code), device=dev)
-        # bf16: the im2col rows (gather + dropout, 3 taps) are stored once and feed the dense LDS-DMA GEMMs of both passes
-        x_rows = torch.empty(n * T, 3 * Dp, dtype=torch.bfloat16, device=dev) if code == _lib.NR_BF16 and n > 0 else None
+        # bf16: the token rows (gather + dropout) are stored once, with a zero row between titles: the im2col row of a token is
+        # 3 * Dp contiguous elements of that buffer, which feeds the LDS-DMA GEMMs of both passes (no 3x im2col copy)
+        x_rows = torch.empty(n * (T + 1) + 1, Dp, dtype=torch.bfloat16, device=dev) if code == _lib.NR_BF16 and n > 0 else None
         d = _lib.ConvDesc(n=n, T=T, D=D, Dp=Dp, N=N, dtype=code, table=ptr(table_p), ids=ids.data_ptr(), ids_stride=stride,
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], w_pack=ptr(w_p), bias=ptr(b_c), x_rows=ptr(x_rows),
-                          ld_rows=3 * Dp, seq_needed=ptr(cfg.get("needed")))
+                          ld_rows=Dp, seq_needed=ptr(cfg.get("needed")))
         check(_lib.lib().nr_conv1d_k3_fwd(C.byref(d), ptr(y), _stream()), "nr_conv1d_k3_fwd")
         ctx.cfg, ctx.dims = cfg, (n, T, D, Dp, N, stride)
         ctx.ids = ids                                   # keeps the (possibly strided) id view alive
@@ -674,7 +675,7 @@ class ConvFunction(Function):
         db = ctx.targets[1] if direct else torch.zeros(N, dtype=torch.float32, device=dev)
         d = _lib.ConvDesc(n=n, T=T, D=D, Dp=Dp, N=N, dtype=code, table=ptr(table_p), ids=ctx.ids.data_ptr(), ids_stride=stride,
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], w_pack=ptr(w_p), bias=ptr(b_c), x_rows=ptr(ctx.x_rows),
-                          ld_rows=3 * Dp, seq_nz=seq_nz, seq_needed=ptr(cfg.get("needed")))
+                          ld_rows=Dp, seq_nz=seq_nz, seq_needed=ptr(cfg.get("needed")))
         bwd_ws = _ws(_lib.lib().nr_conv_workspace_bytes(C.byref(d)), dev) if ctx.x_rows is not None else None
         d.bwd_ws, d.bwd_ws_bytes = ptr(bwd_ws), (bwd_ws.numel() * 4 if bwd_ws is not None else 0)
         check(_lib.lib().nr_conv1d_k3_bwd(C.byref(d), ptr(dy), ptr(dwp), ptr(db), _stream()), "nr_conv1d_k3_bwd")
