@@ -208,6 +208,11 @@ def price_kernel(label, avg_ms, struct, dtype):
         n, L, N, q = _dims(label, r"n=(\d+),L=(\d+),N=(\d+),q=(\d+)")
         by = n * L * (N + q) * esz * (1 if "fwd" in name else 1) + n * L * q * esz * (0 if "fwd" in name else 1)
         return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}
+    if name.startswith("conv_rows"):
+        n, T, Dp = _dims(label, r"n=(\d+),T=(\d+),Dp=(\d+)")
+        frac = struct.get("live_gradient_slabs", 1.0) if name.endswith("_needed") else 1.0     # titles near a needed one (approx.)
+        by = n * frac * (T + 2) * Dp * esz * 2                  # gathered table rows read + token rows (and zero rows) written
+        return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}
     if name.startswith("rows_materialize"):
         M, K = _dims(label, r"M(?:max)?=(\d+),K=(\d+)")
         if name.endswith("_needed"):
