@@ -1142,28 +1142,56 @@ __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
   const int hgroups = (a.heads + AW - 1) / AW;
-  for (long sb = blockIdx.x; sb < a.n; sb += gridDim.x)
+  // Items = (sequence, head group), all head groups of a sequence back to back in one workgroup (its table rows / qkv rows
+  // stay hot in L1/L2).  The six slices (2 row blocks x Q, K, V) of the NEXT item are requested before this item is computed
+  // -- a load -> wait -> compute chain per item was most of this kernel's time (the id -> row -> slice chain of the gather
+  // source twice over): gather ids are fetched one sequence ahead, slices one item ahead.
+  Slice t[2][3];
+  int idr[2] = {0, 0};                                   // GATHER: table rows of this lane's tokens (row blocks 0 / 1) of the sequence being loaded
+  auto load_ids = [&](long sb) {
+    if (GATHER) {
+      const size_t row0 = (size_t)sb * L;
+      const int r = lane & 31;
+      idr[0] = r < L ? a.ids[row0 + r] : 0;
+      idr[1] = 32 + r < L ? a.ids[row0 + 32 + r] : 0;
+    }
+  };
+  auto load = [&](long sb, int hgi) {
+    const int hraw = hgi * AW + wid;
+    const bool active = hraw < a.heads;
+    const int head = active ? hraw : 0, Lw = active ? L : 0;
+    const size_t row0 = (size_t)sb * L;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int Lr = clampL(Lw, rb);
+      if (GATHER) {
+        const int r = lane & 31, part = lane >> 5;
+        const bf16_t* rowp = qkv + (size_t)idr[rb] * 3 * N + head * d;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = 4 * (2 * q + part);
+            t[rb][w].v[q] = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+            if (r < Lr && c < d) t[rb][w].v[q] = *reinterpret_cast<const bf16x4*>(rowp + w * N + c);
+          }
+      } else {
+        const bf16_t* src = qkv + row0 * 3 * N + head * d;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) slice_load(t[rb][w], src + (size_t)32 * rb * 3 * N + w * N, 3 * N, Lr, d, lane);
+      }
+    }
+  };
+  long sb = blockIdx.x;
+  if (sb >= a.n) return;
+  load_ids(sb);
+  load(sb, 0);
+  for (; sb < a.n; sb += gridDim.x)
     for (int hgi = 0; hgi < hgroups; ++hgi) {
       const int hraw = hgi * AW + wid;
       const bool active = hraw < a.heads;
       const int head = active ? hraw : 0, Lw = active ? L : 0;
       const size_t row0 = (size_t)sb * L;
-      const bf16_t* src = qkv + row0 * 3 * N + head * d;
-      // all six slices (2 row blocks x Q, K, V) are requested before the first one is written to LDS: six loads in flight
-      // per lane instead of one (the load -> wait -> ds_write chain per slice was this kernel's whole forward time)
-      Slice t[2][3];
-#pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        const int Lr = clampL(Lw, rb);
-        if (GATHER) {                                  // qkv is a [rows, 3N] table of projections, row of token r = ids[row0 + r]
-          const int32_t* idp = a.ids + row0 + 32 * rb;
-#pragma unroll
-          for (int w = 0; w < 3; ++w) slice_load_g(t[rb][w], qkv, 3 * N, idp, w * N + head * d, Lr, d, lane);
-        } else {
-#pragma unroll
-          for (int w = 0; w < 3; ++w) slice_load(t[rb][w], src + (size_t)32 * rb * 3 * N + w * N, 3 * N, Lr, d, lane);
-        }
-      }
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
         const int Lr = clampL(Lw, rb);
@@ -1173,6 +1201,13 @@ __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
       }
       sMask[lane] = (lane < Lw) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
       __syncthreads();
+      // next item -> registers (in flight during the MFMAs below)
+      if (hgi + 1 < hgroups) {
+        load(sb, hgi + 1);
+      } else if (sb + gridDim.x < a.n) {
+        load_ids(sb + gridDim.x);
+        load(sb + gridDim.x, 0);
+      }
 #pragma unroll 1
       for (int qb = 0; qb < 2; ++qb) {
         f32x16 s0, s1;
