@@ -1572,15 +1572,19 @@ __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restr
     const uint32_t slot = lds0 + (kk % NS) * STAGE;
     const bool real = kk < nsteps;
     const int bk = real ? blk(kk) : 0;
+    const bf16_t* rowp[RT];                        // one 64-bit row address per row tile and stage, not per DMA
+#pragma unroll
+    for (int i = 0; i < RT; ++i) rowp[i] = A + (size_t)arow[i] * lda + c8;
 #pragma unroll
     for (int u = 0; u < PW; ++u) {
       const int p = wid + NW * u;                  // wave-uniform
       if (real && p < APIECES) {
         const int i = p / KS, s2 = p - i * KS;
-        int ar = arow[0];
+        const bf16_t* rp = rowp[0];
 #pragma unroll
-        for (int ii = 1; ii < RT; ++ii) ar = i == ii ? arow[ii] : ar;
-        dma16(A + (size_t)ar * lda + min(32 * s2 + c8, K - 8), slot + p * 1024);
+        for (int ii = 1; ii < RT; ++ii) rp = i == ii ? rowp[ii] : rp;
+        // (K tail: the last k-step may reach past K; the chunk is clamped back -- B is zero there, see nr_launch_gemm_nt)
+        dma16(rp + min(32 * s2, K - 8 - c8), slot + p * 1024);
       } else if (COMPACT && real && p == P_RIDER) {
         // rider: the row numbers of this block (R ints), then those of the block NS-1 steps ahead (R ints)
         const int half = lane / (R / 4), bb = half == 0 ? bk : blk(kk + NS - 1);
@@ -1620,7 +1624,12 @@ __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restr
 
 #pragma unroll 1
   for (int k = 0; k < nsteps; ++k) {
-    wait_vmcnt_le((NS - 2) * PW + min(k, NS - 1) * S);
+    if (k >= NS - 1) {                             // steady state: one immediate
+      constexpr int STEADY = (NS - 2) * PW + (NS - 1) * S;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
+    } else {
+      wait_vmcnt_le((NS - 2) * PW + k * S);
+    }
     __builtin_amdgcn_s_barrier();                  // stage k is in LDS for everyone; everyone is done with stage k-1
     const char* st = smem + (k % NS) * STAGE;
     const int b = blk(k);
@@ -1673,8 +1682,10 @@ __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restr
       }
       auto pack4 = [&](f32x4 v, int lcol) {
         if (EPI == EPI_STORE_TANH) {
+          // tanh x = 1 - 2 / (e^2x + 1) on v_exp_f32 / v_rcp_f32 (abs. error ~1e-7, the result is rounded to bf16 next):
+          // libm's tanhf is ~35 instructions per value, 16 values per lane and step -- it, not memory, bound this kernel
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+          for (int r = 0; r < 4; ++r) v[r] = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * v[r]) + 1.f);
         }
         if (PB) {
           const f32x4 gq = *reinterpret_cast<const f32x4*>(grow + lcol);
