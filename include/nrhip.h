@@ -153,6 +153,10 @@ typedef struct {
                          REQUIRED when nr_mhsa_fwd was given row_ws: on the bf16 title-level path the forward then leaves
                          the qkv rows of all-padding sequences unwritten (the attention kernels substitute the bias), and the
                          backward attention has to do the same.                                                   */
+  int bwd_phase;      /* nr_mhsa_bwd only.  0: the whole backward.  1: everything but the weight / bias gradients (flags, attention
+                         backward, dx / table gradient) ; 2: only dw_qkv / db_qkv, after a phase-1 call with the same
+                         descriptor and row_ws.  The split lets a data-parallel host start the all-reduce of the (large)
+                         table gradient while the weight-gradient GEMM still runs.  Not in deterministic mode.      */
 } nr_mhsa_desc;
 
 /* qkv: [n*L, 3N] dtype (saved for backward); y: [n*L, N] dtype.

@@ -620,6 +620,9 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
   const MhsaWs W = mhsa_ws_layout(d->n, d->L, d->src_kind == NR_SRC_GATHER ? d->table_rows : 0);
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
+  NR_CHECK_ARG(d->bwd_phase >= 0 && d->bwd_phase <= 2, "mhsa_bwd: bwd_phase=%d", d->bwd_phase);
+  const bool ph_main = d->bwd_phase != 2;          // flags, attention backward, dx / table gradient
+  const bool ph_dw = d->bwd_phase != 1;            // weight / bias gradients
   // row_ws_ready: the forward compacted the rows and (when the attention kernels support it) left the qkv rows of
   // padding tokens unwritten -- the backward attention must substitute the bias exactly as the forward one did
   const uint32_t* tmask = nullptr;
@@ -640,17 +643,19 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
       M >= 4096 && nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, dqkv) && (((uintptr_t)dy) & 7) == 0 &&
       nr_gemm_tn_slabs_ok(3 * N, d->ld_rows, M, 3 * N, Kp)) {
     slab_ws = d->row_ws + W.slab;
-    if (d->seq_nz != nullptr) {                    // the consumer of y already knows which sequences got a gradient
-      NR_CHECK_HIP(hipMemcpyAsync(slab_ws, d->seq_nz, (size_t)d->n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-    } else if ((rc = nr_launch_title_flags(dy, d->n, d->L, N, slab_ws, s))) {      // one pass over dy (bf16 [M, N])
-      return rc;
+    if (ph_main) {                                 // (phase 2 finds the lists of its phase-1 call in row_ws)
+      if (d->seq_nz != nullptr) {                  // the consumer of y already knows which sequences got a gradient
+        NR_CHECK_HIP(hipMemcpyAsync(slab_ws, d->seq_nz, (size_t)d->n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+      } else if ((rc = nr_launch_title_flags(dy, d->n, d->L, N, slab_ws, s))) {      // one pass over dy (bf16 [M, N])
+        return rc;
+      }
+      if ((rc = nr_launch_live_slabs(slab_ws, d->n, d->L, s))) return rc;
     }
-    if ((rc = nr_launch_live_slabs(slab_ws, d->n, d->L, s))) return rc;
     const bool no_skip = nr_opt(NR_OPT_NO_ATTN_SKIP) != 0;
     if (tmask != nullptr && !no_skip) {
       // the attention backward walks a list that leaves out the all-padding sequences no live slab comes near
       seq_ws = d->row_ws + W.seq;
-      if ((rc = nr_launch_seq_list(slab_ws, tmask, d->n, d->L, seq_ws, s))) return rc;
+      if (ph_main && (rc = nr_launch_seq_list(slab_ws, tmask, d->n, d->L, seq_ws, s))) return rc;
     }
   }
   // x_rows written under "needed" flags (nr_mhsa_fwd: skip_far) are complete only where a live slab can reach: the slab
@@ -659,9 +664,9 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
                  d->x_rows != nullptr && M >= 4096 && (3 * N) % 8 == 0 && M % 32 == 0 && nr_gemm_tn_slabs_ok(3 * N, d->ld_rows, M, 3 * N, Kp) &&
                  !no_slabs) || slab_ws != nullptr,
                "mhsa_bwd: x_rows were materialised under seq_needed: qkv / dqkv / dy must be 8-byte aligned so that the live-slab path runs");
-  if ((rc = nr_launch_attn(true, d->dtype, qkv, d->mask, nullptr, dy, dqkv, d->n, d->L, d->heads, d->d_head,
-                           nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr, seq_ws ? seq_ws + 4 : nullptr,
-                           seq_ws)))
+  if (ph_main && (rc = nr_launch_attn(true, d->dtype, qkv, d->mask, nullptr, dy, dqkv, d->n, d->L, d->heads, d->d_head,
+                                      nr_make_drop(d->p_out, d->seed_out), s, tmask, tmask ? d->b_qkv : nullptr,
+                                      seq_ws ? seq_ws + 4 : nullptr, seq_ws)))
     return rc;
   // dW_qkv[3N, d_model] += dQKV^T . X ; db += colsum(dQKV).  X: the rows saved by the forward when present.
   RowSrc Xs = A;
@@ -671,6 +676,7 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
   }
   const bool want_dx = dx != nullptr || dtable != nullptr;
   DetScope det(s);
+  NR_CHECK_ARG(!det.on() || d->bwd_phase == 0, "mhsa_bwd: deterministic mode runs the backward in one call (bwd_phase = 0)");
   if (det.on()) {
     NR_CHECK_ARG(dtable == nullptr || d->table_rows > 0, "mhsa_bwd: deterministic mode needs table_rows in the descriptor");
     det.add(dw_qkv, (size_t)3 * N * d->d_model);
@@ -678,17 +684,10 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
     if (dtable != nullptr) det.add(dtable, (size_t)d->table_rows * d->d_model);
     if ((rc = det.begin(true, false))) return rc;
   }
-  const bool fork = want_dx && side_enabled() && M >= 65536 && !det.on();
+  const bool fork = want_dx && side_enabled() && M >= 65536 && !det.on() && d->bwd_phase == 0;
   hipStream_t s2 = s;
   if (fork && (rc = side_fork(s, &s2))) return rc;
-  if (slab_ws != nullptr) {
-    if ((rc = nr_launch_gemm_tn_slabs(dqkv, 3 * N, d->x_rows, d->ld_rows, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model,
-                                      slab_ws + d->n + 4, slab_ws + d->n, s)))
-      return rc;
-  } else if ((rc = nr_launch_gemm_tn(d->dtype, dqkv, 3 * N, Xs, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model, s))) {
-    return rc;
-  }
-  if (want_dx) {
+  if (want_dx && ph_main) {
     hipStream_t s = s2;   // the input-gradient GEMM goes to the side stream
     NR_CHECK_ARG(w_qkv_t != nullptr && ldwt >= 3 * N, "mhsa_bwd: w_qkv_t [d_model, >=3N] needed for dx / dtable");
     RowSrc G = dense_rows(dqkv, 3 * N, 3 * N);
@@ -718,6 +717,17 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
       NR_CHECK_ARG(d->d_model % 4 == 0, "mhsa_bwd: d_model=%d must be a multiple of 4", d->d_model);
       EpiArgs ep = store_epi(dx, d->ldx, d->dtype, nullptr, 0);
       rc = nr_launch_gemm_nt(d->dtype, G, w_qkv_t, ldwt, M, d->d_model, 3 * N, EPI_STORE, ep, s);
+    }
+  }
+  if (rc) return rc;
+  // (after the table gradient: in a phased call the host's all-reduce of that gradient overlaps this GEMM)
+  if (ph_dw) {
+    if (slab_ws != nullptr) {
+      if ((rc = nr_launch_gemm_tn_slabs(dqkv, 3 * N, d->x_rows, d->ld_rows, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model,
+                                        slab_ws + d->n + 4, slab_ws + d->n, s)))
+        return rc;
+    } else if ((rc = nr_launch_gemm_tn(d->dtype, dqkv, 3 * N, Xs, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model, s))) {
+      return rc;
     }
   }
   if (fork) {

@@ -357,8 +357,19 @@ class MHSAFunction(Function):
             else:
                 dx = torch.empty(n, L, ldx, dtype=torch_dtype(code), device=dev)
         d.row_ws, d.row_ws_bytes = ptr(row_ws), (row_ws.numel() * 4 if row_ws is not None else 0)
-        check(_lib.lib().nr_mhsa_bwd(C.byref(d), ptr(qkv), ptr(dy), ptr(dqkv), ptr(w_t), w_t.shape[1] if w_t is not None else 0,
-                                     ptr(dw), ptr(db), ptr(dx), ptr(dtable), _stream()), "nr_mhsa_bwd")
+        def run(phase):
+            d.bwd_phase = phase
+            check(_lib.lib().nr_mhsa_bwd(C.byref(d), ptr(qkv), ptr(dy), ptr(dqkv), ptr(w_t), w_t.shape[1] if w_t is not None else 0,
+                                         ptr(dw), ptr(db), ptr(dx), ptr(dtable), _stream()), "nr_mhsa_bwd")
+        # A data-parallel bucket wants to know the moment the (large) table gradient is complete: the backward then runs in two
+        # phases -- table gradient first, the hook starts its all-reduce, the weight-gradient GEMM runs underneath it.
+        ready = cfg.get("table_grad_ready") if (gather and cfg.get("table_grad") is not None and _det_scratch is None) else None
+        if ready is not None:
+            run(1)
+            ready()
+            run(2)
+        else:
+            run(0)
         gx = (None if cfg.get("table_grad") is not None else dtable) if gather else dx
         if bucket is not None:
             return (gx, None, None, None, None, None, None, None, None, None)
@@ -418,6 +429,7 @@ def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int, code: int, mask=None, ids=None, 
         cfg["table_shape"] = tuple(table.shape)
         if table.requires_grad and torch.is_grad_enabled():
             cfg["table_grad"] = grad_target(table)
+            cfg["table_grad_ready"] = getattr(table, "_nr_grad_ready", None)     # parallel.FlatBucket, world > 1
         return MHSAFunction.apply(table, wq, bq, wk, bk, wv, bv, ids, mask, cfg)
     ch = chunk(code)
     if x.shape[-1] % ch:

@@ -104,7 +104,15 @@ class FlatBucket:
                     groups.append((m, len(segments)))        # weights segment, then biases segment
                     segments += [ws, bs]
                     seen.update(id(p) for p in ws + bs)
-        segments += [[p] for p in params if id(p) not in seen]
+        rest = [p for p in params if id(p) not in seen]
+        # the largest parameter (the word-embedding table: 9 of NRMS's 10 M values) goes LAST: its gradient is all-reduced on
+        # its own as soon as the backward has produced it (see _early_allreduce), everything in front of it in one more call
+        big = max(rest, key=lambda p: p.numel()) if rest else None
+        if big is not None and big.numel() >= (1 << 20):
+            rest = [p for p in rest if p is not big] + [big]
+        else:
+            big = None
+        segments += [[p] for p in rest]
         order, offs, seg_off, off = [], [], [], 0
         for seg in segments:
             off = _align(off)
@@ -133,6 +141,10 @@ class FlatBucket:
             m._nr_flat = {"w": self.param[o_w:o_w + 3 * N * d_model].view(3 * N, d_model), "b": self.param[o_b:o_b + 3 * N],
                           "gw": self.grad[o_w:o_w + 3 * N * d_model].view(3 * N, d_model), "gb": self.grad[o_b:o_b + 3 * N]}
         self._model = model
+        self._early_work, self._big_off = None, None
+        if big is not None and self.world > 1:
+            self._big_off = offs[[id(q) for q in order].index(id(big))]
+            big._nr_grad_ready = self._early_allreduce       # ops.MHSAFunction.backward calls it once the table gradient is complete
         if broadcast and self.world > 1:             # DDP construction semantics (src/main.py:82): rank 0's parameters win
             dist.broadcast(self.param, src=0, group=group)
         self._params_changed()
@@ -148,10 +160,24 @@ class FlatBucket:
     def zero_grad(self):
         self.grad.zero_()
 
+    def _early_allreduce(self):
+        """Called from the backward pass right after the table-gradient kernel was enqueued (one backward per step): its
+        all-reduce starts now, on the collective's own stream, underneath the rest of the backward."""
+        if self.world > 1 and self._early_work is None:
+            self._early_work = dist.all_reduce(self.grad[self._big_off:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def allreduce(self):
-        """The one collective of a step: SUM over ranks (the 1/world of the mean is applied inside the Adam kernel)."""
+        """The collective(s) of a step: SUM over ranks (the 1/world of the mean is applied inside the Adam kernel).  One call
+        over the whole flat gradient -- or, when the backward announced the table gradient early, one over what lies in front
+        of it plus the wait for the early one."""
         if self.world > 1:
-            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
+            if self._early_work is not None:
+                if self._big_off > 0:
+                    dist.all_reduce(self.grad[:self._big_off], op=dist.ReduceOp.SUM, group=self.group)
+                self._early_work.wait()
+                self._early_work = None
+            else:
+                dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=self.group)
 
     def adam_step(self, zero_grad=True):
         if not self.param.is_cuda:

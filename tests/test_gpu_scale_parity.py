@@ -217,6 +217,32 @@ def test_flat_bucket_over_rccl_single_rank():
         dist.destroy_process_group()
 
 
+def test_phased_backward_with_early_table_gradient_hook_equals_the_single_call():
+    """Data-parallel overlap: with a `_nr_grad_ready` hook on the word table (parallel.FlatBucket sets it when world > 1) the
+    MHSA backward runs in two library calls -- table gradient first, hook, then the weight gradients (nr_mhsa_desc.bwd_phase).
+    The gradients must be those of the single call, and the hook must fire exactly once per backward, after the table
+    gradient kernel was enqueued (so what it sees at that point in the stream is the complete table gradient)."""
+    from newsrecommendation_amd import parallel
+    grads, seen = [], []
+    for hooked in (False, True):
+        cfg, sd, m, (hist, mask, cand, label) = _nrms_case("bf16", 71)
+        m.train()
+        fb = parallel.FlatBucket(m, lr=1e-3)
+        table = m.news_encoder.embedding_matrix.weight
+        if hooked:
+            table._nr_grad_ready = lambda: seen.append(table._nr_grad.clone())     # stream-ordered snapshot at hook time
+        torch.manual_seed(7)
+        loss, _ = m(hist.cuda(), mask.cuda(), cand.cuda(), label.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append(fb.grad.clone())
+    assert len(seen) == 1
+    scale = grads[0].abs().max().item()
+    assert (grads[0] - grads[1]).abs().max().item() <= 1e-4 * scale           # order of the fp32 atomics only
+    tg = m.news_encoder.embedding_matrix.weight._nr_grad
+    assert (seen[0] - tg).abs().max().item() == 0.0                            # nothing touched the table gradient after the hook
+
+
 @pytest.mark.parametrize("model_name", ["NRMS", "NAML"])
 def test_deterministic_mode_gives_bit_identical_gradients(model_name):
     """ops.set_deterministic(True): every gradient several workgroups add into (dW, db, the word-table gradient, pad_doc) is
