@@ -93,7 +93,7 @@ enum NrOpt {
   NR_OPT_NO_ROW_SUB,     // 1: the projection writes the bias into padding rows (bias_rows) instead of per-row substitution
   NR_OPT_ATTN_BWD_OCC4,  // 1: the specialised attention backward built for 4 waves per SIMD (128 VGPRs, a few spills) instead of 3
   NR_OPT_NT_ABLATE,      // measurement only (results are WRONG): tiled LDS-DMA NT kernel without 1: output stores, 2: MFMAs, 4: operand DMA, 8: epilogue; 64: phase stamps (nr_debug_nt_trace)
-  NR_OPT_NT_WREG,        // 1 (default): skinny-K bf16 NT GEMMs with the weights held in registers (persistent, LDS ring of activation rows; a 4-wave, two-workgroups-per-CU flavour was slower: 0.28 vs 0.24 ms); 0: tile kernels
+  NR_OPT_NT_WREG,        // 1 (default): skinny-K bf16 NT GEMMs with the weights held in registers (persistent, LDS ring of activation rows); 3: the same with 16-row instead of 32-row stages for the QKV shape; 0: tile kernels
   NR_OPT_NO_SCATTER_SORT, // 1: the table-gradient GEMM walks the live rows in batch order instead of token-id order
   NR_OPT_COUNT
 };

@@ -1471,7 +1471,7 @@ enum { WREG_DENSE = 0,    // blocks b0 + k * stride of the dense rows
        WREG_COMPACT = 1,  // the same over the compacted live rows (ep.row_count / ep.row_idx); row numbers ride with the stages
        WREG_LIST = 2 };   // dense rows, but only blocks that touch a sequence flagged in ep.seq_nz (list built in the prologue)
 
-template <int EPI, int TPW, int KS, int RT, int MODE>
+template <int EPI, int TPW, int KS, int RT, int MODE, bool SEQ = false>
 struct WregCfg {
   static constexpr int NW = 8, R = 16 * RT;
   static constexpr int GCOLS = NW * TPW * 16;                         // columns of a group
@@ -1490,10 +1490,13 @@ struct WregCfg {
   static_assert((NS - 2) * PW + (NS - 1) * S <= 62, "vmcnt is a 6-bit counter");
 };
 
-template <int EPI, int TPW, int KS, int RT, int MODE>
+// SEQ: the RT row tiles of a stage are computed one after the other through ONE set of accumulators (MFMAs, epilogue, MFMAs,
+// epilogue): a 32-row stage -- half the barriers and stage issues per row -- without the 20 extra accumulator registers
+// that the QKV instantiation (200 registers of weights) does not have.
+template <int EPI, int TPW, int KS, int RT, int MODE, bool SEQ = false>
 __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B, int ldb,
                                                            int Mmax, int Ntot, int K, EpiArgs ep, int ngroups) {
-  using Cfg = WregCfg<EPI, TPW, KS, RT, MODE>;
+  using Cfg = WregCfg<EPI, TPW, KS, RT, MODE, SEQ>;
   constexpr int NW = Cfg::NW, R = Cfg::R, NS = Cfg::NS, PW = Cfg::PW, STAGE = Cfg::STAGE, S = Cfg::S, GCOLS = Cfg::GCOLS;
   constexpr int APIECES = Cfg::APIECES, GT = Cfg::GT, GP = Cfg::GP;
   constexpr bool COMPACT = MODE == WREG_COMPACT, LISTED = MODE == WREG_LIST, PB = EPI == EPI_POOLBWD;
@@ -1647,27 +1650,32 @@ __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restr
     }
     issue_stage(k + NS - 1, ar);
 
-    f32x4 acc[RT][TPW];
+    constexpr int RP = SEQ ? 1 : RT, NPASS = RT / RP;     // row tiles per pass through the accumulators
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+    f32x4 acc[RP][TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + (wid * TPW + t) * 16 + 4 * g);
 #pragma unroll
-      for (int i = 0; i < RT; ++i) acc[i][t] = bv;
+      for (int i = 0; i < RP; ++i) acc[i][t] = bv;
     }
     if (wcol0 < Ntot) {                            // wave-uniform: a wave whose tiles are all beyond N only keeps step with the others
 #pragma unroll
       for (int s2 = 0; s2 < KS; ++s2) {
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
+        for (int ii = 0; ii < RP; ++ii) {
+          const int i = q * RP + ii;
           const bf16x8 af = *reinterpret_cast<const bf16x8*>(st + (i * KS + s2) * 1024 + offA);
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][s2], af, acc[i][t], 0, 0, 0);
+          for (int t = 0; t < TPW; ++t) acc[ii][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][s2], af, acc[ii][t], 0, 0, 0);
         }
       }
     }
-    // ---- epilogue: exactly S stores per wave
+    // ---- epilogue: exactly S stores per wave and stage
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
+    for (int ii = 0; ii < RP; ++ii) {
+      const int i = q * RP + ii;
       const int m = b * R + 16 * i + fr;
       const bool rok = m < M;
       bf16_t* crow = Cb + (size_t)mout[i] * ep.ldc;
@@ -1699,19 +1707,20 @@ __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restr
       for (int t = 0; t < TPW; t += 2) {
         const int lc = (wid * TPW + t) * 16 + 4 * g;         // this lane's first column inside the group, tile t
         if (t + 1 < TPW) {
-          const uint2 xv = pack4(acc[i][t], lc), yv = pack4(acc[i][t + 1 < TPW ? t + 1 : t], lc + 16);
+          const uint2 xv = pack4(acc[ii][t], lc), yv = pack4(acc[ii][t + 1 < TPW ? t + 1 : t], lc + 16);
           const auto s0 = __builtin_amdgcn_permlane16_swap(xv.x, yv.x, false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(xv.y, yv.y, false, false);
           const int col = wcol0 + (t + (g & 1)) * 16 + (g >> 1) * 8;
           uint4* dst = (rok && col + 8 <= Ntot) ? reinterpret_cast<uint4*>(crow + col) : dump_g;
           *dst = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         } else {
-          const uint2 xv = pack4(acc[i][t], lc);
+          const uint2 xv = pack4(acc[ii][t], lc);
           const int col = wcol0 + t * 16 + 4 * g;
           uint2* dst = (rok && col + 4 <= Ntot) ? reinterpret_cast<uint2*>(crow + col) : reinterpret_cast<uint2*>(dump_g);
           *dst = xv;
         }
       }
+    }
     }
   }
 }
@@ -1729,9 +1738,9 @@ __global__ __launch_bounds__(256) void zero_dead_blocks_kernel(const int32_t* __
   for (int u = threadIdx.x; u < rows * row_chunks; u += 256) dst[u] = make_uint4(0, 0, 0, 0);
 }
 
-template <int EPI, int TPW, int KS, int RT, int MODE>
+template <int EPI, int TPW, int KS, int RT, int MODE, bool SEQ = false>
 int launch_nt_wreg_m(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
-  using Cfg = WregCfg<EPI, TPW, KS, RT, MODE>;
+  using Cfg = WregCfg<EPI, TPW, KS, RT, MODE, SEQ>;
   static int cus = 0;
   if (cus == 0) {
     int dev = 0, n = 0;
@@ -1747,7 +1756,7 @@ int launch_nt_wreg_m(const RowSrc& A, const void* B, int ldb, int M, int N, int 
   const int max_steps = (nblk + 8 * Q - 1) / (8 * Q);
   const size_t smem = (size_t)Cfg::LIST + (MODE == WREG_LIST ? (size_t)(max_steps + 8) * sizeof(int) : 0);
   NR_CHECK_ARG(smem <= 160 * 1024, "gemm_nt_wreg: %d row blocks per workgroup do not fit the LDS list", max_steps);
-  auto kern = gemm_nt_wreg_kernel<EPI, TPW, KS, RT, MODE>;
+  auto kern = gemm_nt_wreg_kernel<EPI, TPW, KS, RT, MODE, SEQ>;
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   if (EPI == EPI_POOLBWD && MODE == WREG_LIST) {
     hipLaunchKernelGGL(zero_dead_blocks_kernel, dim3(nblk), dim3(256), 0, stream, ep.seq_nz, ep.L, M, Cfg::R, (uint4*)ep.C, ep.ldc / 8);
@@ -2559,8 +2568,11 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
                                      : (ep.seq_nz ? "gemm_nt_wreg_needed[bf16,epi=%d,Mmax=%d,N=%d,K=%d]" : "gemm_nt_wreg[bf16,epi=%d,M=%d,N=%d,K=%d]");
       if (epi == EPI_STORE && !tile_skip && K > 288 && K <= 320 && N >= 320) {
         NrProfScope ps(stream, lbl, epi, M, N, K);
-        return ep.row_count ? launch_nt_wreg_m<EPI_STORE, 5, 10, 1, WREG_COMPACT>(A, B, ldb, M, N, K, ep, stream)
-                            : launch_nt_wreg_m<EPI_STORE, 5, 10, 1, WREG_DENSE>(A, B, ldb, M, N, K, ep, stream);
+        if (nr_opt(NR_OPT_NT_WREG) == 3)           // 16-row stages (one row tile per barrier)
+          return ep.row_count ? launch_nt_wreg_m<EPI_STORE, 5, 10, 1, WREG_COMPACT>(A, B, ldb, M, N, K, ep, stream)
+                              : launch_nt_wreg_m<EPI_STORE, 5, 10, 1, WREG_DENSE>(A, B, ldb, M, N, K, ep, stream);
+        return ep.row_count ? launch_nt_wreg_m<EPI_STORE, 5, 10, 2, WREG_COMPACT, true>(A, B, ldb, M, N, K, ep, stream)
+                            : launch_nt_wreg_m<EPI_STORE, 5, 10, 2, WREG_DENSE, true>(A, B, ldb, M, N, K, ep, stream);
       }
       if (epi == EPI_STORE_TANH && ep.row_count == nullptr && K > 384 && K <= 416 && N <= 256 && (!tile_skip || flags)) {
         NrProfScope ps(stream, lbl, epi, M, N, K);
