@@ -2048,7 +2048,7 @@ int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw
 bool eligible(int ldc, int ldx, int M, int N, int K) {
   const bool off = nr_opt(NR_OPT_NO_TN3) != 0;
   // long contractions only: at the user level (M = 25 600) the ring fill per split costs more than it hides (0.31 vs 0.18 ms)
-  return !off && M % TBM == 0 && M >= 200000 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0 && ldc % 8 == 0 && ldx % 8 == 0;
+  return !off && M % TBM == 0 && M >= nr_opt(NR_OPT_TN3_MIN_M) && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0 && ldc % 8 == 0 && ldx % 8 == 0;
 }
 int launch(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
            int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr, int xgap = 0) {
