@@ -2047,7 +2047,8 @@ int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw
 // rows a multiple of the 32-row slab, at least 8 columns on both sides (tail clamping), 16-byte aligned rows
 bool eligible(int ldc, int ldx, int M, int N, int K) {
   const bool off = nr_opt(NR_OPT_NO_TN3) != 0;
-  // long contractions only: at the user level (M = 25 600) the ring fill per split costs more than it hides (0.31 vs 0.18 ms)
+  // (round 1 kept the user level, M = 25 600, on tn2: 0.31 vs 0.18 ms then; with one round of splits and >= 16 slabs per
+  //  split tn3 now wins there too: 0.067 vs 0.089 ms for [25 600, 1200] x [25 600, 400])
   return !off && M % TBM == 0 && M >= nr_opt(NR_OPT_TN3_MIN_M) && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0 && ldc % 8 == 0 && ldx % 8 == 0;
 }
 int launch(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
