@@ -2559,6 +2559,7 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
     const bool tile_skip = (epi == EPI_STORE || epi == EPI_STORE_TANH) && ep.seq_nz != nullptr && ep.row_count == nullptr;
     // skinny K, bf16 out: weights-in-registers kernels (see gemm_nt_wreg_kernel); shapes with an instantiation:
     //   QKV projection    STORE       K in (288, 320], N >= 320        5 column tiles per wave, 16-row steps
+    //   user-level QKV    STORE       K in (384, 416], N >= 320        3 column tiles per wave, 32-row stages (two passes)
     //   pooling fc1       STORE_TANH  K in (384, 416], N <= 256        2 column tiles per wave, 32-row steps
     //   pooling dX        POOLBWD     K in (192, 224], N <= 512        4 column tiles per wave, 32-row steps
     // ("_needed" there: only 32-row blocks that touch a flagged sequence are computed)
@@ -2574,6 +2575,10 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
                               : launch_nt_wreg_m<EPI_STORE, 5, 10, 1, WREG_DENSE>(A, B, ldb, M, N, K, ep, stream);
         return ep.row_count ? launch_nt_wreg_m<EPI_STORE, 5, 10, 2, WREG_COMPACT, true>(A, B, ldb, M, N, K, ep, stream)
                             : launch_nt_wreg_m<EPI_STORE, 5, 10, 2, WREG_DENSE, true>(A, B, ldb, M, N, K, ep, stream);
+      }
+      if (epi == EPI_STORE && !tile_skip && ep.row_count == nullptr && K > 384 && K <= 416 && N >= 320) {   // user-level QKV (d_model = 400)
+        NrProfScope ps(stream, lbl, epi, M, N, K);
+        return launch_nt_wreg_m<EPI_STORE, 3, 13, 2, WREG_DENSE, true>(A, B, ldb, M, N, K, ep, stream);
       }
       if (epi == EPI_STORE_TANH && ep.row_count == nullptr && K > 384 && K <= 416 && N <= 256 && (!tile_skip || flags)) {
         NrProfScope ps(stream, lbl, epi, M, N, K);
