@@ -79,6 +79,15 @@ int nr_get_option(const char* name);
  * src/model/NRMS.py:70-73 and src/main.py:79.                                              */
 int nr_cast_pad(const float* src, int rows, int cols, int ld_src, void* dst, int ld_dst, int dtype,
                 int transpose, nr_stream_t stream);
+/* The same for up to NR_CAST_BATCH_MAX operands in ONE launch (the weights a training step re-packs after each optimizer
+ * step are small: one 6-us launch each otherwise).  `jobs` is host memory; all destinations share `dtype`.            */
+#define NR_CAST_BATCH_MAX 16
+typedef struct {
+  const float* src;
+  void* dst;
+  int rows, cols, ld_src, ld_dst, transpose;
+} nr_cast_job;
+int nr_cast_pad_batch(const nr_cast_job* jobs, int n, int dtype, nr_stream_t stream);
 /* Conv1d weight [N, D, 3] (src/model/NAML.py:27-32) -> tap-major GEMM operand [N, 3*Dp]
  * (dst[n, tap*Dp + d] = w[n, d, tap]); unpack is the inverse on an fp32 gradient
  * (accumulate != 0: dw += ..., else dw = ...).                                               */

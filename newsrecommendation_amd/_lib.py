@@ -39,6 +39,14 @@ class ConvDesc(C.Structure):
                 ("seq_needed", C.c_void_p)]
 
 
+CAST_BATCH_MAX = 16          # NR_CAST_BATCH_MAX of include/nrhip.h
+
+
+class CastJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int), ("cols", C.c_int), ("ld_src", C.c_int),
+                ("ld_dst", C.c_int), ("transpose", C.c_int)]
+
+
 class PoolDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("L", C.c_int), ("N", C.c_int), ("q", C.c_int), ("dtype", C.c_int), ("x", C.c_void_p),
                 ("mask", C.c_void_p), ("w1", C.c_void_p), ("ldw1", C.c_int), ("b1", C.c_void_p), ("w2", C.c_void_p),
@@ -76,6 +84,7 @@ SIGNATURES = {
     "nr_check_ids": [_vp, _i, _i, _i, _vp, _vp],
     "nr_check_labels": [_vp, _i, _i, _vp, _vp],
     "nr_cast_pad": [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp],
+    "nr_cast_pad_batch": [_vp, _i, _i, _vp],
     "nr_pack_conv_w": [_vp, _i, _i, _vp, _i, _i, _vp],
     "nr_unpack_conv_dw": [_vp, _i, _i, _i, _vp, _i, _vp],
     "nr_embed_gather_fwd": [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp],

@@ -467,6 +467,39 @@ __global__ void cast_pad_kernel(const float* __restrict__ src, int rows, int col
   }
 }
 
+// several cast_pad jobs in one launch (the weights a training step re-packs after every optimizer step are tiny: nine
+// 6-us launches).  blk0[j] = first block of job j; a block works on 1024 consecutive destination elements of its job.
+struct CastJobs {
+  const float* src[NR_CAST_BATCH_MAX];
+  void* dst[NR_CAST_BATCH_MAX];
+  int rows[NR_CAST_BATCH_MAX], cols[NR_CAST_BATCH_MAX], ld_src[NR_CAST_BATCH_MAX], ld_dst[NR_CAST_BATCH_MAX], transpose[NR_CAST_BATCH_MAX];
+  int blk0[NR_CAST_BATCH_MAX + 1];
+  int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void cast_pad_batch_kernel(CastJobs J) {
+  int j = 0;
+  while (j + 1 < J.n && (int)blockIdx.x >= J.blk0[j + 1]) ++j;        // uniform
+  const int rows = J.rows[j], cols = J.cols[j], ld_src = J.ld_src[j], ld_dst = J.ld_dst[j], transpose = J.transpose[j];
+  const float* __restrict__ src = J.src[j];
+  T* __restrict__ dst = reinterpret_cast<T*>(J.dst[j]);
+  const size_t total = (size_t)(transpose ? cols : rows) * ld_dst;
+  const size_t i0 = (size_t)((int)blockIdx.x - J.blk0[j]) * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const size_t i = i0 + u * 256 + threadIdx.x;
+    if (i >= total) break;
+    const int r = (int)(i / ld_dst), c = (int)(i - (size_t)r * ld_dst);
+    float v = 0.f;
+    if (!transpose) {
+      if (c < cols) v = src[(size_t)r * ld_src + c];
+    } else {
+      if (c < rows) v = src[(size_t)c * ld_src + r];
+    }
+    dst[i] = (T)v;
+  }
+}
+
 template <typename T>
 __global__ void pack_conv_w_kernel(const float* __restrict__ w, int N, int D, T* __restrict__ dst, int Dp) {
   const size_t total = (size_t)N * 3 * Dp;
@@ -601,6 +634,33 @@ int nr_cast_pad(const float* src, int rows, int cols, int ld_src, void* dst, int
     hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, src, rows, cols, ld_src, (bf16_t*)dst, ld_dst, transpose);
   else
     hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, src, rows, cols, ld_src, (float*)dst, ld_dst, transpose);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_cast_pad_batch(const nr_cast_job* jobs, int n, int dtype, nr_stream_t stream) {
+  NR_CHECK_ARG(jobs != nullptr && n >= 1 && n <= NR_CAST_BATCH_MAX, "cast_pad_batch: 1..%d jobs", NR_CAST_BATCH_MAX);
+  CastJobs J;
+  J = CastJobs();
+  J.n = n;
+  int blocks = 0;
+  for (int j = 0; j < n; ++j) {
+    const nr_cast_job& q = jobs[j];
+    NR_CHECK_ARG(q.src && q.dst && q.rows > 0 && q.cols > 0, "cast_pad_batch: job %d null/empty", j);
+    NR_CHECK_ARG(q.ld_dst >= (q.transpose ? q.rows : q.cols) && q.ld_src >= q.cols, "cast_pad_batch: job %d leading dimensions too small", j);
+    J.src[j] = q.src; J.dst[j] = q.dst; J.rows[j] = q.rows; J.cols[j] = q.cols; J.ld_src[j] = q.ld_src; J.ld_dst[j] = q.ld_dst;
+    J.transpose[j] = q.transpose;
+    J.blk0[j] = blocks;
+    const size_t total = (size_t)(q.transpose ? q.cols : q.rows) * q.ld_dst;
+    NR_CHECK_ARG(total < ((size_t)1 << 30), "cast_pad_batch: job %d too large for the batched kernel", j);
+    blocks += (int)((total + 1023) / 1024);
+  }
+  J.blk0[n] = blocks;
+  NR_DEVICE_GUARD(stream, jobs[0].dst);
+  hipStream_t s = (hipStream_t)stream;
+  NrProfScope ps(s, "cast_pad_batch[jobs=%d]", n);
+  if (dtype == NR_BF16) hipLaunchKernelGGL(cast_pad_batch_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, J);
+  else hipLaunchKernelGGL(cast_pad_batch_kernel<float>, dim3(blocks), dim3(256), 0, s, J);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }

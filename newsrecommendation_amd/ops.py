@@ -158,6 +158,67 @@ def draw_seed() -> int:
     return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
 
 
+class _PackCache:
+    """Packed copies of the small weights that live in a flat parameter bucket (parallel.FlatBucket registers its buffer).
+    A training step asks for the same ~9 packs (Q|K|V and att_fc1 weights, plain and transposed) after every optimizer
+    step; each used to be its own 6-us launch.  Here the first request after a parameter update (ops.param_epoch moved, or a
+    torch-side in-place write bumped the tensor's version) refreshes EVERY pack seen so far in ONE launch (nr_cast_pad_batch).
+    Tensors outside a registered bucket are never cached."""
+    MAX_ELEMS = 1 << 21                # (larger operands -- embedding tables -- go through _TableCache)
+
+    def __init__(self):
+        self._ranges = []              # (first byte, last byte + 1) of registered flat parameter buffers
+        self._e = {}                   # key -> [src view, dst, transpose, code, stamp]
+
+    def register_buffer(self, t: torch.Tensor) -> None:
+        """t: the bucket's flat parameter tensor.  Its packs are served for as long as that tensor object lives."""
+        self._ranges.append((weakref.ref(t), t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()))
+
+    def clear(self) -> None:
+        self._ranges, self._e = [], {}
+
+    def _purge(self) -> None:
+        dead = [(a, b) for r, a, b in self._ranges if r() is None]
+        if dead:
+            self._ranges = [x for x in self._ranges if x[0]() is not None]
+            for k in [k for k in self._e if any(a <= k[0] < b for a, b in dead)]:
+                del self._e[k]
+
+    def _cached_kind(self, src) -> bool:
+        self._purge()
+        p = src.data_ptr()
+        return src.numel() <= self.MAX_ELEMS and any(a <= p < b for _, a, b in self._ranges)
+
+    def get(self, src, code, transpose, ld):
+        if not self._cached_kind(src):
+            return None
+        key = (src.data_ptr(), tuple(src.shape), bool(transpose), int(ld), int(code), src.device.index)
+        stamp = (param_epoch, src._version)
+        ent = self._e.get(key)
+        if ent is not None and ent[4] == stamp:
+            return ent[1]
+        if ent is None:
+            rows, cols = src.shape
+            dst = torch.empty(cols if transpose else rows, ld, dtype=torch_dtype(code), device=src.device)
+            ent = self._e[key] = [src, dst, bool(transpose), int(code), None]
+        # refresh this entry and every other stale one of the same dtype / device in one launch
+        todo = [e for k, e in self._e.items()
+                if e[3] == code and k[5] == src.device.index and e[4] != (param_epoch, e[0]._version)][:_lib.CAST_BATCH_MAX]
+        if not any(e is ent for e in todo):
+            todo = [ent] + todo[:_lib.CAST_BATCH_MAX - 1]
+        jobs = (_lib.CastJob * len(todo))()
+        for j, e in zip(jobs, todo):
+            r, c = e[0].shape
+            j.src, j.dst, j.rows, j.cols, j.ld_src, j.ld_dst, j.transpose = ptr(e[0]), ptr(e[1]), r, c, c, e[1].shape[1], int(e[2])
+        check(_lib.lib().nr_cast_pad_batch(jobs, len(todo), code, _stream()), "nr_cast_pad_batch")
+        for e in todo:
+            e[4] = (param_epoch, e[0]._version)
+        return ent[1]
+
+
+pack_cache = _PackCache()
+
+
 def pack(src: torch.Tensor, code: int, transpose: bool = False, ld: Optional[int] = None) -> torch.Tensor:
     """fp32 [rows, cols] -> compute-dtype GEMM operand, leading dimension zero-padded to a 16-byte chunk."""
     _need_gpu(src)
@@ -168,6 +229,9 @@ def pack(src: torch.Tensor, code: int, transpose: bool = False, ld: Optional[int
     drows, dcols = (cols, rows) if transpose else (rows, cols)
     # bf16: leading dimension rounded up to 32 and zero padded, so the LDS-DMA GEMM can run whole 32-deep k-steps
     ld = ld or round_up(dcols, 32 if code == NR_BF16 else chunk(code))
+    cached = pack_cache.get(src, code, transpose, ld)
+    if cached is not None:
+        return cached
     dst = torch.empty(drows, ld, dtype=torch_dtype(code), device=src.device)
     check(_lib.lib().nr_cast_pad(ptr(src), rows, cols, cols, ptr(dst), ld, code, int(transpose), _stream()), "nr_cast_pad")
     return dst

@@ -141,6 +141,8 @@ class FlatBucket:
             m._nr_flat = {"w": self.param[o_w:o_w + 3 * N * d_model].view(3 * N, d_model), "b": self.param[o_b:o_b + 3 * N],
                           "gw": self.grad[o_w:o_w + 3 * N * d_model].view(3 * N, d_model), "gb": self.grad[o_b:o_b + 3 * N]}
         self._model = model
+        from . import ops
+        ops.pack_cache.register_buffer(self.param)     # the small weights' packed copies are refreshed in one launch per step
         self._early_work, self._big_off = None, None
         if big is not None and self.world > 1:
             self._big_off = offs[[id(q) for q in order].index(id(big))]

@@ -236,3 +236,42 @@ def test_flat_bucket_checkpoint_round_trip(tmp_path):
     with torch.no_grad():
         a, b = m(*batches[1]), m2(*batches[1])
     assert torch.equal(a[1], b[1])
+
+
+def test_pack_cache_follows_parameter_updates():
+    """ops.pack_cache: the packed (bf16, padded / transposed) copies of weights that live in a FlatBucket are served from a
+    cache and refreshed -- all of them in one nr_cast_pad_batch launch -- when the fused Adam kernel (ops.param_epoch) or a
+    torch-side in-place write (tensor version) changed the parameters.  Tensors outside a bucket are never cached."""
+    from newsrecommendation_amd import ops, parallel
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(400, 200), torch.nn.Linear(200, 1200)).cuda()
+    fb = parallel.FlatBucket(net, lr=1e-2)
+    ws = [net[0].weight, net[1].weight]
+
+    def expect(w, transpose):
+        ref = (w.detach().t() if transpose else w.detach()).to(torch.bfloat16)
+        return ref
+
+    def check_all():
+        outs = []
+        for w in ws:
+            for tr in (False, True):
+                pk = ops.pack(w, ops.NR_BF16, transpose=tr)
+                ref = expect(w, tr)
+                assert torch.equal(pk[:, :ref.shape[1]], ref)
+                assert float(pk[:, ref.shape[1]:].abs().sum()) == 0.0          # zero padded
+                outs.append(pk)
+        return outs
+
+    a = check_all()
+    b = check_all()
+    assert all(x.data_ptr() == y.data_ptr() for x, y in zip(a, b))               # second round: served from the cache
+    fb.grad.fill_(0.5)
+    fb.adam_step()                                                               # parameters change behind autograd's back
+    check_all()
+    with torch.no_grad():
+        ws[0].mul_(2.0)                                                          # torch-side in-place write
+    check_all()
+    loose = torch.randn(64, 96, device="cuda")
+    p1, p2 = ops.pack(loose, ops.NR_BF16), ops.pack(loose, ops.NR_BF16)
+    assert p1.data_ptr() != p2.data_ptr()                                        # not in a bucket: packed afresh each time
