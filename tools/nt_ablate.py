@@ -8,6 +8,7 @@ from newsrecommendation_amd import ops, _lib
 from gemm_probe import timeit
 
 def main():
+    _lib.set_option("NT_WREG", 0)      # these tools take the TILED LDS-DMA kernel apart (the default for these shapes is gemm_nt_wreg_kernel)
     M = int(os.environ.get("M", 253440))
     for name, N, K in [("qkv", 1200, 304), ("fc1", 200, 400), ("poolbwd-like", 400, 200), ("dx-like", 304, 1200)]:
         a = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)

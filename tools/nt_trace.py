@@ -7,6 +7,7 @@ import numpy as np, torch
 from newsrecommendation_amd import ops, _lib
 
 def main():
+    _lib.set_option("NT_WREG", 0)      # these tools take the TILED LDS-DMA kernel apart (the default for these shapes is gemm_nt_wreg_kernel)
     M = int(os.environ.get("M", 253440))
     N, K = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1200, 304)
     a = (torch.randn(M, K, device="cuda") * 0.5).to(torch.bfloat16)
