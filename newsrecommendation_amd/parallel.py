@@ -165,7 +165,10 @@ class FlatBucket:
     def _early_allreduce(self):
         """Called from the backward pass right after the table-gradient kernel was enqueued (one backward per step): its
         all-reduce starts now, on the collective's own stream, underneath the rest of the backward."""
-        if self.world > 1 and self._early_work is None:
+        if self.world > 1:
+            if self._early_work is not None:
+                raise RuntimeError("FlatBucket: a second backward pass before step() -- the table gradient of the first one is "
+                                   "already being all-reduced (one backward per optimizer step, as src/main.py:104-110)")
             self._early_work = dist.all_reduce(self.grad[self._big_off:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def allreduce(self):
