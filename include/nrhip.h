@@ -372,8 +372,11 @@ int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, s
  * writes one line per label "label<TAB>launches<TAB>total_ms\n" into buf (host), clears the log and
  * returns the number of bytes written (or a negative NR_ERR_* code).                          */
 /* on = 1: every launch; on = 2: only launches that work on >= 65 536 rows (a pair of event records costs ~3 us of
- * stream time, which adds up over the ~60 small launches of a step); on = 0: off.               */
+ * stream time, which adds up over the ~60 small launches of a step); on = 3: only launches whose label starts with the
+ * prefix given to nr_prof_filter (one kernel: the timed region of a benchmark pays for two event records per step);
+ * on = 0: off.                                                                                  */
 int nr_prof_enable(int on);
+int nr_prof_filter(const char* label_prefix);
 int nr_prof_collect(char* buf, size_t n);
 /* Phase stamps of the tiled LDS-DMA NT GEMM (measurement only; option NT_ABLATE bit 64, tools/nt_trace.py): copies up to
  * n (<= 8 * 4096) 64-bit words -- per workgroup 7 s_memrealtime stamps and the HW_ID register -- after a device sync. */

@@ -109,6 +109,7 @@ SIGNATURES = {
     "nr_dropout_mask": [_vp, _u32, _f, _u32, _vp],
     "nr_prof_enable": [_i],
     "nr_prof_collect": [C.c_char_p, C.c_size_t],
+    "nr_prof_filter": [C.c_char_p],
     "nr_debug_nt_trace": [_vp, _i],
 }
 
@@ -179,8 +180,10 @@ def get_option(name: str) -> int:
     return int(lib().nr_get_option(name.encode()))
 
 
-def prof_enable(on) -> None:
-    """False/0 off, True/1 every launch, 2 only launches over >= 65 536 rows."""
+def prof_enable(on, only=None) -> None:
+    """False/0 off, True/1 every launch, 2 only launches over >= 65 536 rows, 3 only launches whose label starts with `only`."""
+    if only is not None:
+        check(lib().nr_prof_filter(str(only).encode()), "nr_prof_filter")
     check(lib().nr_prof_enable(int(on)), "nr_prof_enable")
 
 

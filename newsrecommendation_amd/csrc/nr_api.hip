@@ -83,8 +83,10 @@ long prof_label_rows(const char* label) {
   }
   return -1;
 }
+std::string g_prof_filter;   // mode 3: only labels that start with this
 int prof_begin(const char* label, hipStream_t s) {
   if (g_prof_mode == 2 && prof_label_rows(label) < 65536) return -1;   // a pair of event records costs ~3 us of stream time
+  if (g_prof_mode == 3 && strncmp(label, g_prof_filter.c_str(), g_prof_filter.size()) != 0) return -1;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfEntry e;
   e.label = label;
@@ -339,7 +341,13 @@ int nr_version(void) { return 200; }
 
 int nr_prof_enable(int on) {
   g_nr_prof_on = on != 0;
-  g_prof_mode = on == 2 ? 2 : 1;
+  g_prof_mode = on == 2 ? 2 : (on == 3 ? 3 : 1);
+  return NR_OK;
+}
+
+int nr_prof_filter(const char* label_prefix) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_filter = label_prefix ? label_prefix : "";
   return NR_OK;
 }
 
