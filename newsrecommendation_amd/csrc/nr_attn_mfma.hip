@@ -1201,6 +1201,10 @@ __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
       }
       sMask[lane] = (lane < Lw) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
       __syncthreads();
+      // this lane's 16 + 16 key-mask values (0 beyond L), once per item instead of once per query block and element
+      float mk0[16], mk1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { mk0[r] = sMask[rowof(r, h2)]; mk1[r] = sMask[32 + rowof(r, h2)]; }
       // next item -> registers (in flight during the MFMAs below)
       if (hgi + 1 < hgroups) {
         load(sb, hgi + 1);
@@ -1215,20 +1219,22 @@ __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
         mm_rr(s0, sK, sQ + qb * IMG, lane);         // keys 0..31   x queries of block qb
         mm_rr(s1, sK + IMG, sQ + qb * IMG, lane);   // keys 32..63
-        float m = -INFINITY;
+        // softmax over the keys of one query (a lane pair): exp(scale*s - m) = exp2(s*c - m*c), c = scale*log2(e): the raw
+        // scores go through one fma + v_exp_f32; keys >= L have mask 0 (the key block 0 is always complete: L > 32)
+        const float c2 = a.scale * 1.44269504088896341f;
+        float mr = -INFINITY;                          // max of the RAW scores over the valid keys (scale > 0)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          s0[r] *= a.scale; s1[r] *= a.scale;
-          if (rowof(r, h2) < L) m = fmaxf(m, s0[r]);
-          if (32 + rowof(r, h2) < L) m = fmaxf(m, s1[r]);
+          mr = fmaxf(mr, s0[r]);
+          if (32 + rowof(r, h2) < L) mr = fmaxf(mr, s1[r]);
         }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
+        const float m = mr * a.scale, mc = -mr * c2;
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int j = rowof(r, h2);
-          const float e0 = (j < L) ? __expf(s0[r] - m) * sMask[j] : 0.f;
-          const float e1 = (32 + j < L) ? __expf(s1[r] - m) * sMask[32 + j] : 0.f;
+          const float e0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, mc)) * mk0[r];
+          const float e1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, mc)) * mk1[r];
           s0[r] = e0; s1[r] = e1;
           sum += e0 + e1;
         }
