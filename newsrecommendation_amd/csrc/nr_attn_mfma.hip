@@ -685,6 +685,13 @@ __device__ __forceinline__ void panel_load_g(Panel<PT>& r, const bf16_t* __restr
     if (pc.hh(t) < hcount) r.v[t] = *reinterpret_cast<const bf16x4*>(table + (size_t)ids[pc.row(t)] * ld + coff + pc.q4(t));
   }
 }
+// ... FULL flavour: every slot is a real piece (see make_pieces), no predicates
+template <int PT>
+__device__ __forceinline__ void panel_load_g_all(Panel<PT>& r, const bf16_t* __restrict__ table, int ld, const int32_t* __restrict__ ids,
+                                                 int coff, const Pieces<PT>& pc) {
+#pragma unroll
+  for (int t = 0; t < PT; ++t) r.v[t] = *reinterpret_cast<const bf16x4*>(table + (size_t)ids[pc.row(t)] * ld + coff + pc.q4(t));
+}
 template <bool DROP, int PT, bool FULL = false>
 __device__ __forceinline__ void panel_put(const Panel<PT>& r, bf16_t* img0, const Pieces<PT>& pc, const DropCfg& drop, uint32_t eidx0,
                                           int erow) {
@@ -810,9 +817,15 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
     dead_next = (SUB && dead_seq) || (FULL && skip_next);   // FULL: a skipped sequence loads like a dead one (rows ignored)
     if (GATHER) {
       const int32_t* idp = a.ids + (size_t)sq_next * L;
-      panel_load_g(rq, qkv, N3, idp, hoff, pc, hcount);
-      panel_load_g(rk, qkv, N3, idp, N + hoff, pc, hcount);
-      panel_load_g(rv, qkv, N3, idp, 2 * N + hoff, pc, hcount);
+      if (FULL) {
+        panel_load_g_all(rq, qkv, N3, idp, hoff, pc);
+        panel_load_g_all(rk, qkv, N3, idp, N + hoff, pc);
+        panel_load_g_all(rv, qkv, N3, idp, 2 * N + hoff, pc);
+      } else {
+        panel_load_g(rq, qkv, N3, idp, hoff, pc, hcount);
+        panel_load_g(rk, qkv, N3, idp, N + hoff, pc, hcount);
+        panel_load_g(rv, qkv, N3, idp, 2 * N + hoff, pc, hcount);
+      }
     } else if (ROWSUB) {
       tm_item = skip_next ? 0u : tm_seq;                 // a skipped sequence loads nothing real either
       const uint32_t so = (uint32_t)sq_next * (uint32_t)(L * N3);
@@ -1611,7 +1624,9 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
       else if (full) p3 ? go(bwd_kernel<HM, 3, SB, true>) : go(bwd_kernel<HM, 4, SB, true>);
       else p3 ? go(bwd_kernel<HM, 3, SB>) : go(bwd_kernel<HM, 4, SB>);
     } else if (!SB && a.ids != nullptr) {
-      p3 ? go(fwd_kernel<HM, 3, false, true>) : go(fwd_kernel<HM, 4, false, true>);
+      // eval's title-level gather: the specialised, unpredicated instantiation for the reference's default shape too
+      if (title30) go(fwd_kernel<HM, 3, false, true, true, 30, 20, 20>);
+      else p3 ? go(fwd_kernel<HM, 3, false, true>) : go(fwd_kernel<HM, 4, false, true>);
     } else if (title30) {
       go(fwd_kernel<HM, 3, SB, false, true, 30, 20, 20>);
     } else if (full) {
