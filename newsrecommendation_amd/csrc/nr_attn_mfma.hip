@@ -1142,7 +1142,9 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
 // Every matrix is two row-block images; queries are processed one 32-row block at a time against both key blocks.
 __device__ __forceinline__ int clampL(int L, int rb) { return min(32, max(0, L - 32 * rb)); }
 
-template <bool GATHER>
+// LC / DC / HC: compile-time sequence length, head width and head count (0 = from the arguments), as for fwd_kernel: the
+// reference's user level (50 clicks, 20 heads of 20) gets its own instantiation
+template <bool GATHER, int LC = 0, int DC = 0, int HC = 0>
 __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1151,10 +1153,10 @@ __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
   float* sMask = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + (size_t)AW * 7 * IMG) + wid * 64;
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
   bf16_t* y = reinterpret_cast<bf16_t*>(a.y);
-  const int N = a.N, L = a.L, d = a.d, h2 = lane >> 5;
+  const int L = LC ? LC : a.L, d = DC ? DC : a.d, heads = HC ? HC : a.heads, N = heads * d, h2 = lane >> 5;
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
-  const int hgroups = (a.heads + AW - 1) / AW;
+  const int hgroups = (heads + AW - 1) / AW;
   // Items = (sequence, head group), all head groups of a sequence back to back in one workgroup (its table rows / qkv rows
   // stay hot in L1/L2).  The six slices (2 row blocks x Q, K, V) of the NEXT item are requested before this item is computed
   // -- a load -> wait -> compute chain per item was most of this kernel's time (the id -> row -> slice chain of the gather
@@ -1171,7 +1173,7 @@ __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
   };
   auto load = [&](long sb, int hgi) {
     const int hraw = hgi * AW + wid;
-    const bool active = hraw < a.heads;
+    const bool active = hraw < heads;
     const int head = active ? hraw : 0, Lw = active ? L : 0;
     const size_t row0 = (size_t)sb * L;
 #pragma unroll
@@ -1202,7 +1204,7 @@ __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
   for (; sb < a.n; sb += gridDim.x)
     for (int hgi = 0; hgi < hgroups; ++hgi) {
       const int hraw = hgi * AW + wid;
-      const bool active = hraw < a.heads;
+      const bool active = hraw < heads;
       const int head = active ? hraw : 0, Lw = active ? L : 0;
       const size_t row0 = (size_t)sb * L;
 #pragma unroll
@@ -1598,8 +1600,15 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
       NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bwd64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64));
       hipLaunchKernelGGL(bwd64_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
     } else {
-      if (a.ids != nullptr) hipLaunchKernelGGL(fwd64_kernel<true>, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
-      else hipLaunchKernelGGL(fwd64_kernel<false>, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+      const bool user50 = a.L == 50 && a.d == 20 && a.heads == 20 && !nr_opt(NR_OPT_ATTN_GENERIC);     // the reference's defaults
+      if (a.ids != nullptr) {
+        if (user50) hipLaunchKernelGGL((fwd64_kernel<true, 50, 20, 20>), dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+        else hipLaunchKernelGGL(fwd64_kernel<true>, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+      } else if (user50) {
+        hipLaunchKernelGGL((fwd64_kernel<false, 50, 20, 20>), dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+      } else {
+        hipLaunchKernelGGL(fwd64_kernel<false>, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+      }
     }
     NR_CHECK_LAUNCH();
     return NR_OK;
