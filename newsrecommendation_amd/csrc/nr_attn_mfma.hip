@@ -1272,6 +1272,7 @@ __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
     }
 }
 
+template <int LC = 0, int DC = 0, int HC = 0>
 __global__ __launch_bounds__(AW * 64) void bwd64_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1282,14 +1283,14 @@ __global__ __launch_bounds__(AW * 64) void bwd64_kernel(AttnMArgs a) {
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
   const bf16_t* dy = reinterpret_cast<const bf16_t*>(a.dy);
   bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.dqkv);
-  const int N = a.N, L = a.L, d = a.d, h2 = lane >> 5, li = lane & 31;
+  const int L = LC ? LC : a.L, d = DC ? DC : a.d, heads = HC ? HC : a.heads, N = heads * d, h2 = lane >> 5, li = lane & 31;
   DropCfg nodrop;
   nodrop.key = 0; nodrop.thresh = 0; nodrop.scale = 1.f;
-  const int hgroups = (a.heads + AW - 1) / AW;
+  const int hgroups = (heads + AW - 1) / AW;
   for (long sb = blockIdx.x; sb < a.n; sb += gridDim.x)
     for (int hgi = 0; hgi < hgroups; ++hgi) {
       const int hraw = hgi * AW + wid;
-      const bool active = hraw < a.heads;
+      const bool active = hraw < heads;
       const int head = active ? hraw : 0, Lw = active ? L : 0;
       const size_t row0 = (size_t)sb * L;
       const bf16_t* src = qkv + row0 * 3 * N + head * d;
@@ -1597,8 +1598,13 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   if (a.L > 32) {
     const size_t smem64 = bwd ? AW * (9 * IMG * sizeof(bf16_t) + 256 * sizeof(float)) : AW * (7 * IMG * sizeof(bf16_t) + 64 * sizeof(float));
     if (bwd) {
-      NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bwd64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64));
-      hipLaunchKernelGGL(bwd64_kernel, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+      if (a.L == 50 && a.d == 20 && a.heads == 20 && !nr_opt(NR_OPT_ATTN_GENERIC)) {
+        NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bwd64_kernel<50, 20, 20>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64));
+        hipLaunchKernelGGL((bwd64_kernel<50, 20, 20>), dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+      } else {
+        NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bwd64_kernel<>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem64));
+        hipLaunchKernelGGL(bwd64_kernel<>, dim3((unsigned)blocks), dim3(AW * 64), smem64, stream, a);
+      }
     } else {
       const bool user50 = a.L == 50 && a.d == 20 && a.heads == 20 && !nr_opt(NR_OPT_ATTN_GENERIC);     // the reference's defaults
       if (a.ids != nullptr) {
