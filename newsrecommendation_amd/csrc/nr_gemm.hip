@@ -2657,17 +2657,94 @@ __global__ __launch_bounds__(1024) void live_slabs_kernel(const int32_t* __restr
   };
   int c = 0;
   walk([&](int, bool lv) { c += lv ? 1 : 0; });
-  sCnt[tid] = c;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {                    // inclusive Hillis-Steele scan
-    const int v = tid >= o ? sCnt[tid - o] : 0;
-    __syncthreads();
-    sCnt[tid] += v;
-    __syncthreads();
+  // block scan: inside each wave by shuffles, then the 16 wave totals by the first wave (2 barriers instead of the 20 of a
+  // Hillis-Steele scan over LDS)
+  const int lane = tid & 63, wv = tid >> 6;
+  int v = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
   }
-  int pos = sCnt[tid] - c;
+  if (lane == 63) sCnt[wv] = v;
+  __syncthreads();
+  if (wv == 0) {
+    int w = lane < 16 ? sCnt[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int t = __shfl_up(w, o, 64);
+      if (lane >= o) w += t;
+    }
+    if (lane < 16) sCnt[16 + lane] = w;                   // inclusive totals of waves 0 .. lane
+  }
+  __syncthreads();
+  int pos = v - c + (wv > 0 ? sCnt[16 + wv - 1] : 0);
   walk([&](int s, bool lv) { if (lv) list[pos++] = s; });
+  if (tid == 1023) sCnt[1023] = sCnt[16 + 15];            // (the line below reports the grand total)
   if (tid == 1023) *count = sCnt[1023];
+}
+}  // namespace
+
+// The same in two launches, which is what runs for up to 128 K slabs: the per-slab test (two integer divisions, 2-3 flag
+// loads) over the whole chip, then ONE workgroup that only counts bytes, scans and writes the ordered list.  The single
+// workgroup doing the per-slab work for all 26 400 slabs was instruction bound on its one CU: 30 us a call, twice a step.
+namespace {
+__global__ __launch_bounds__(256) void slab_flags_kernel(const int32_t* __restrict__ title_nz, int n, int L, int nslab,
+                                                         unsigned char* __restrict__ flags) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= nslab) return;
+  const int t0 = (32 * s) / L, t1 = min(n - 1, (32 * s + 31) / L);
+  bool lv = false;
+  for (int t = t0; t <= t1; ++t) lv |= title_nz[t] != 0;
+  flags[s] = lv ? 1 : 0;
+}
+// flags: nslab bytes that may overlap the END of `list` (they are staged into LDS before the first list entry is written)
+__global__ __launch_bounds__(1024) void slab_list_kernel(const unsigned char* __restrict__ flags, int nslab, int32_t* __restrict__ count,
+                                                         int32_t* __restrict__ list) {
+  __shared__ int sCnt[32];
+  extern __shared__ __attribute__((aligned(16))) unsigned char sFlag[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int words = (nslab + 3) / 4;
+  const uint32_t* fw = reinterpret_cast<const uint32_t*>(flags);
+  for (int base = 0; base < words; base += 8 * 1024) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int w = base + u * 1024 + tid;
+      v[u] = w < words ? fw[w] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int w = base + u * 1024 + tid;
+      if (w < words) reinterpret_cast<uint32_t*>(sFlag)[w] = v[u];
+    }
+  }
+  __syncthreads();
+  const int per = (nslab + 1023) / 1024, s0 = tid * per, s1 = min(nslab, s0 + per);
+  int c = 0;
+  for (int s2 = s0; s2 < s1; ++s2) c += sFlag[s2];
+  int v = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  if (lane == 63) sCnt[wv] = v;
+  __syncthreads();
+  if (wv == 0) {
+    int w = lane < 16 ? sCnt[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int t = __shfl_up(w, o, 64);
+      if (lane >= o) w += t;
+    }
+    if (lane < 16) sCnt[16 + lane] = w;
+  }
+  __syncthreads();
+  int pos = v - c + (wv > 0 ? sCnt[16 + wv - 1] : 0);
+  for (int s2 = s0; s2 < s1; ++s2)
+    if (sFlag[s2]) list[pos++] = s2;
+  if (tid == 0) *count = sCnt[16 + 15];
 }
 }  // namespace
 
@@ -2806,10 +2883,18 @@ int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, in
 int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream) {
   const int M = n * L, nslab = M / 32;
   NR_CHECK_ARG(ws != nullptr && M % 32 == 0, "live_slabs: bad arguments");
-  NR_CHECK_HIP(hipMemsetAsync(ws + n, 0, 4 * sizeof(int32_t), stream));
+  int32_t* list = ws + n + 4;
+  if (nslab >= 4 && nslab <= 128 * 1024) {
+    // the flag bytes live in the last nslab bytes of the list array (int aligned) until the list kernel has staged them
+    unsigned char* flags = reinterpret_cast<unsigned char*>(list + nslab - (nslab + 3) / 4);
+    hipLaunchKernelGGL(slab_flags_kernel, dim3((nslab + 255) / 256), dim3(256), 0, stream, ws, n, L, nslab, flags);
+    hipLaunchKernelGGL(slab_list_kernel, dim3(1), dim3(1024), (size_t)((nslab + 15) / 16) * 16, stream, flags, nslab, ws + n, list);
+    NR_CHECK_LAUNCH();
+    return NR_OK;
+  }
   const int in_lds = n <= 128 * 1024 ? 1 : 0;
   hipLaunchKernelGGL(live_slabs_kernel, dim3(1), dim3(1024), in_lds ? (size_t)((n + 15) / 16) * 16 : 0, stream, ws, n, L, nslab, ws + n,
-                     ws + n + 4, in_lds);
+                     list, in_lds);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
