@@ -220,8 +220,9 @@ __global__ __launch_bounds__(256) void pool_bwd_kernel(const T* __restrict__ x, 
 
 // out[c] += sum_r in[r*ld + c]: workgroup (x, y) sums rows y, y + gridDim.y, ... of 64 columns and adds its partial
 // with one atomic per column (gridDim.y <= 32 partials per column).
+// Columns [0, split) go to out, columns [split, cols) to out2 (the pooling backward's dw2 | db2 in one launch).
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, int rows, int cols, int ld,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, int split, float* __restrict__ out2) {
   __shared__ float red[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ i
     for (int r = blockIdx.y * 4 + ry; r < rows; r += 4 * gridDim.y) s += in[(size_t)r * ld + c];
   red[ry][cx] = s;
   __syncthreads();
-  if (ry == 0 && c < cols) nr_accum(out + c, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx], nr_fix_on());
+  if (ry == 0 && c < cols)
+    nr_accum(c < split ? out + c : out2 + (c - split), red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx], nr_fix_on());
 }
 
 // ------------------------------------------------------------------------------------------
@@ -586,8 +588,7 @@ int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float
     hipLaunchKernelGGL(pool_bwd_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)x, (const float*)e, w2, alpha, g, ld_g, (float*)dpre, partial, n, L, N, q, pool_spb(n), seq_nz);
   NR_CHECK_LAUNCH();
   const int ysplit = nb >= 512 ? 32 : (nb >= 64 ? 8 : 1);
-  hipLaunchKernelGGL(colsum_kernel, dim3((q + 63) / 64, ysplit), dim3(256), 0, s, partial, nb, q, q + 1, dw2);
-  hipLaunchKernelGGL(colsum_kernel, dim3(1, ysplit), dim3(256), 0, s, partial + q, nb, 1, q + 1, db2);
+  hipLaunchKernelGGL(colsum_kernel, dim3((q + 1 + 63) / 64, ysplit), dim3(256), 0, s, partial, nb, q + 1, q + 1, dw2, q, db2);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
