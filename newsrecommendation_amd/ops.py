@@ -115,7 +115,10 @@ def _enter_backward() -> int:
 
 def _offer_flags(seq, dx, n, flags_ptr, keepalive) -> None:
     global _flag_hint
-    _flag_hint = (seq, dx.data_ptr(), dx.numel(), n, flags_ptr, keepalive) if flags_ptr and dx is not None else None
+    # dx._version: autograd may ADD another consumer's gradient into dx in place (same pointer, same size) before the next
+    # libnrhip backward sees it -- the flags would then drop sequences whose gradient is no longer zero
+    _flag_hint = ((seq, dx.data_ptr(), dx.numel(), n, flags_ptr, keepalive, dx._version, weakref.ref(dx))
+                  if flags_ptr and dx is not None else None)
 
 
 def _take_flags(seq, dy, n):
@@ -123,7 +126,9 @@ def _take_flags(seq, dy, n):
     global _flag_hint
     h, _flag_hint = _flag_hint, None
     if h is not None and h[0] == seq - 1 and h[1] == dy.data_ptr() and h[2] == dy.numel() and h[3] == n:
-        return h[4], h[5]
+        dx = h[7]()
+        if dx is not None and dx._version == h[6] and dy._version == h[6]:
+            return h[4], h[5]
     return 0, None
 
 
@@ -170,30 +175,39 @@ class _PackCache:
         self._ranges = []              # (first byte, last byte + 1) of registered flat parameter buffers
         self._e = {}                   # key -> [src view, dst, transpose, code, stamp]
 
-    def register_buffer(self, t: torch.Tensor) -> None:
-        """t: the bucket's flat parameter tensor.  Its packs are served for as long as that tensor object lives."""
-        self._ranges.append((weakref.ref(t), t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()))
+    def register_buffer(self, t: torch.Tensor, versions=None) -> None:
+        """t: the bucket's flat parameter tensor.  Its packs are served for as long as that tensor object lives.
+        versions: optional callable -> tuple of the version counters of the Parameters that live in `t` (a Parameter whose
+        `.data` was pointed at a view of `t` keeps its own counter, so `t._version` alone misses torch-side writes to it)."""
+        self._ranges.append((weakref.ref(t), t.data_ptr(), t.data_ptr() + t.numel() * t.element_size(), versions))
 
     def clear(self) -> None:
         self._ranges, self._e = [], {}
 
     def _purge(self) -> None:
-        dead = [(a, b) for r, a, b in self._ranges if r() is None]
+        dead = [(a, b) for r, a, b, _ in self._ranges if r() is None]
         if dead:
             self._ranges = [x for x in self._ranges if x[0]() is not None]
             for k in [k for k in self._e if any(a <= k[0] < b for a, b in dead)]:
                 del self._e[k]
 
-    def _cached_kind(self, src) -> bool:
+    def _bucket_versions(self, src):
+        """None: `src` lies in no registered bucket (never cached); else the bucket's parameter-version tuple (or ())."""
         self._purge()
+        if src.numel() > self.MAX_ELEMS:
+            return None
         p = src.data_ptr()
-        return src.numel() <= self.MAX_ELEMS and any(a <= p < b for _, a, b in self._ranges)
+        for _, a, b, versions in self._ranges:
+            if a <= p < b:
+                return versions() if versions is not None else ()
+        return None
 
     def get(self, src, code, transpose, ld):
-        if not self._cached_kind(src):
+        bv = self._bucket_versions(src)
+        if bv is None:
             return None
         key = (src.data_ptr(), tuple(src.shape), bool(transpose), int(ld), int(code), src.device.index)
-        stamp = (param_epoch, src._version)
+        stamp = (param_epoch, src._version, bv)
         ent = self._e.get(key)
         if ent is not None and ent[4] == stamp:
             return ent[1]
@@ -202,8 +216,10 @@ class _PackCache:
             dst = torch.empty(cols if transpose else rows, ld, dtype=torch_dtype(code), device=src.device)
             ent = self._e[key] = [src, dst, bool(transpose), int(code), None]
         # refresh this entry and every other stale one of the same dtype / device in one launch
+        def stamp_of(e):
+            return (param_epoch, e[0]._version, self._bucket_versions(e[0]))
         todo = [e for k, e in self._e.items()
-                if e[3] == code and k[5] == src.device.index and e[4] != (param_epoch, e[0]._version)][:_lib.CAST_BATCH_MAX]
+                if e[3] == code and k[5] == src.device.index and e[4] != stamp_of(e)][:_lib.CAST_BATCH_MAX]
         if not any(e is ent for e in todo):
             todo = [ent] + todo[:_lib.CAST_BATCH_MAX - 1]
         jobs = (_lib.CastJob * len(todo))()
@@ -212,7 +228,7 @@ class _PackCache:
             j.src, j.dst, j.rows, j.cols, j.ld_src, j.ld_dst, j.transpose = ptr(e[0]), ptr(e[1]), r, c, c, e[1].shape[1], int(e[2])
         check(_lib.lib().nr_cast_pad_batch(jobs, len(todo), code, _stream()), "nr_cast_pad_batch")
         for e in todo:
-            e[4] = (param_epoch, e[0]._version)
+            e[4] = stamp_of(e)
         return ent[1]
 
 
@@ -771,8 +787,9 @@ def conv1d_k3_gather(table, w, b, ids, T: int, D: int, code: int, p_in=0.0, need
                            "its [V, T*D] dense gradient is out of scope on this path")
     if CHECK_INDICES:
         check_ids(ids, table.shape[0], "news id")
-    cfg = dict(code=code, T=T, D=D, p_in=float(p_in), seed_in=draw_seed() if p_in > 0 else 0,
-               table_packed=table_cache.get(table, code, row_cols=D), needed=needed)
+    # model.NAML.TitleTable holds the packed operand itself (uploaded block by block); a plain fp32 parameter is packed once
+    packed = table.packed(code) if hasattr(table, "packed") else table_cache.get(table, code, row_cols=D)
+    cfg = dict(code=code, T=T, D=D, p_in=float(p_in), seed_in=draw_seed() if p_in > 0 else 0, table_packed=packed, needed=needed)
     return ConvFunction.apply(w, b, ids, cfg)
 
 

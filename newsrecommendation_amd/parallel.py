@@ -142,11 +142,20 @@ class FlatBucket:
                           "gw": self.grad[o_w:o_w + 3 * N * d_model].view(3 * N, d_model), "gb": self.grad[o_b:o_b + 3 * N]}
         self._model = model
         from . import ops
-        ops.pack_cache.register_buffer(self.param)     # the small weights' packed copies are refreshed in one launch per step
-        self._early_work, self._big_off = None, None
+        # the small weights' packed copies are refreshed in one launch per step; their stamp follows the version counter of
+        # EVERY parameter of the bucket (`p.data = view` leaves each Parameter its own counter: a torch-side in-place write such
+        # as load_state_dict bumps that one, not the flat buffer's)
+        ops.pack_cache.register_buffer(self.param, versions=self._versions)
+        self._early_work, self._big_off, self.early_calls = None, None, 0
         if big is not None and self.world > 1:
-            self._big_off = offs[[id(q) for q in order].index(id(big))]
-            big._nr_grad_ready = self._early_allreduce       # ops.MHSAFunction.backward calls it once the table gradient is complete
+            # The early all-reduce splits the step's collective in two; whether the backward fires it depends on per-process
+            # state (deterministic mode, a trainable table).  Ranks that disagreed would issue collectives of different sizes,
+            # so they agree ONCE, here: one MIN all-reduce of "I would fire it".
+            mine = torch.tensor([1 if ops._det_scratch is None else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(mine, op=dist.ReduceOp.MIN, group=group)
+            if int(mine.item()) == 1:
+                self._big_off = offs[[id(q) for q in order].index(id(big))]
+                big._nr_grad_ready = self._early_allreduce   # ops.MHSAFunction.backward calls it once the table gradient is complete
         if broadcast and self.world > 1:             # DDP construction semantics (src/main.py:82): rank 0's parameters win
             dist.broadcast(self.param, src=0, group=group)
         self._params_changed()
@@ -159,7 +168,15 @@ class FlatBucket:
             ops.table_cache.invalidate(p)
         ops.bump_param_epoch()
 
+    def _versions(self):
+        return tuple(p._version for p in self.params)
+
     def zero_grad(self):
+        """Also the abort path of a step: an early table all-reduce that is still in flight is waited for and dropped, so
+        the next backward starts clean."""
+        if self._early_work is not None:
+            self._early_work.wait()
+            self._early_work = None
         self.grad.zero_()
 
     def _early_allreduce(self):
@@ -170,6 +187,7 @@ class FlatBucket:
                 raise RuntimeError("FlatBucket: a second backward pass before step() -- the table gradient of the first one is "
                                    "already being all-reduced (one backward per optimizer step, as src/main.py:104-110)")
             self._early_work = dist.all_reduce(self.grad[self._big_off:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.early_calls += 1
 
     def allreduce(self):
         """The collective(s) of a step: SUM over ranks (the 1/world of the mean is applied inside the Adam kernel).  One call

@@ -46,9 +46,13 @@ def build_model(args, embedding_matrix, n_category=0, n_subcategory=0):
 
 
 def checkpoint_dict(model, category_dict=None, subcategory_dict=None):
-    """src/main.py:118-142 layout; DDP's 'module.' prefix stripped.  Tensors are cloned: parameters of a FlatBucket model
-    are views of one big buffer, and torch.save would otherwise write that whole buffer once per view."""
-    sd = {(k[len("module."):] if k.startswith("module.") else k): v.detach().clone() for k, v in model.state_dict().items()}
+    """src/main.py:118-142 layout; DDP's 'module.' prefix stripped.  Tensors are copied to the HOST: a device-side clone
+    would double a frozen multi-GB table in HBM at every epoch end, and a host copy also detaches the FlatBucket views from
+    their shared buffer (each entry is saved with its own storage)."""
+    def own(v):
+        t = v.detach().cpu()
+        return t.clone() if t.untyped_storage().nbytes() > t.numel() * t.element_size() else t      # (a view of a CPU bucket)
+    sd = {(k[len("module."):] if k.startswith("module.") else k): own(v) for k, v in model.state_dict().items()}
     return {"model_state_dict": sd, "category_dict": category_dict or {}, "subcategory_dict": subcategory_dict or {}}
 
 
@@ -117,7 +121,8 @@ def train(rank, args, news_index, news_combined, embedding_matrix, category_dict
         model.load_state_dict(load_checkpoint(os.path.join(args.model_dir, args.load_ckpt_name))["model_state_dict"])
     model = model.to(device)                                   # before the optimizer: its state follows the parameters' device
     if getattr(args, "deterministic", False) and on_gpu:       # bit-reproducible gradients (fixed-point integer atomics)
-        ops.set_deterministic(True, elements=sum(p.numel() for p in model.parameters()) + (1 << 20), device=device)
+        # (only trainable outputs are ever registered with the fixed-point scratch: a frozen 575 M-value title table is not)
+        ops.set_deterministic(True, elements=sum(p.numel() for p in model.parameters() if p.requires_grad) + (1 << 20), device=device)
     mode = getattr(args, "dp_mode", None) or ("flat" if on_gpu else "ddp")
     net, bucket, optimizer = model, None, None
     if mode == "flat":

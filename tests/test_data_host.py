@@ -7,6 +7,7 @@ import os
 import random
 
 import numpy as np
+import pytest
 
 from newsrecommendation_amd import data as D
 
@@ -120,3 +121,53 @@ def test_indexed_shards_equal_the_line_by_line_datasets(golden_dir, tmp_path):
                 a, b = st.offsets[i], st.offsets[i + 1]
                 assert st.hist[i].tolist() == hist and st.mask[i].tolist() == mask
                 assert st.cand[a:b].tolist() == cand and st.label[a:b].tolist() == labels
+
+
+def test_bf16_shards_round_trip_and_title_table_state_dict(tmp_path):
+    """Row f3, second half: the bf16 shard format (token rows [rows*T, Dp], round-to-nearest-even, zero padded) against
+    torch's own fp32 -> bf16 cast, and the checkpoint surface of `NAML.TitleTable` on the CPU (key, shape, values;
+    the packed operand itself is GPU-only and says so)."""
+    import torch
+    from types import SimpleNamespace
+    from newsrecommendation_amd import formats as F
+    from newsrecommendation_amd.model import NAML
+    rnd = np.random.RandomState(1)
+    rows, T, Dm = 45, 5, 12
+    emb = (rnd.randn(rows, T * Dm) * np.exp(rnd.randn(rows, 1) * 4)).astype(np.float32)      # many binades, ties included
+    emb[0] = 0
+    emb[3, :4] = [1.00390625, 1.01171875, -1.00390625, 3.0e-39]                              # exact ties + a denormal
+    bits = F.f32_to_bf16_bits(emb)
+    want = torch.from_numpy(emb).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(bits, want)
+    d = str(tmp_path)
+    path = F.write_bf16_shards(d, emb, Dm, rows_per_shard=16)
+    sh = F.read_bf16_shards(d)
+    assert (sh.rows, sh.T, sh.D, sh.Dp) == (rows, T, Dm, 32) and len(sh.files) == 3 and sh.shape == emb.shape
+    blocks = list(sh.blocks())
+    assert [a for a, _ in blocks] == [0, 16, 32] and all(isinstance(b, np.memmap) for _, b in blocks)
+    full = np.concatenate([np.asarray(b) for _, b in blocks])
+    assert np.array_equal(full[:, :Dm].reshape(rows, T * Dm), want) and not full[:, Dm:].any()
+    assert np.array_equal(sh.to_float32(), torch.from_numpy(emb).to(torch.bfloat16).float().numpy())
+    assert isinstance(F.load_title_table(d, prefer_bf16_shards=True), F.Bf16Shards)
+    F.write_news_embeddings(d, emb.reshape(rows, T, Dm))
+    assert isinstance(F.load_title_table(d), np.memmap)
+
+    args = SimpleNamespace(drop_rate=0.2, num_words_title=T, word_embedding_dim=Dm, use_category=False, use_subcategory=False,
+                           news_dim=16, news_query_vector_dim=8, user_query_vector_dim=8, category_emb_dim=4, freeze_embedding=True,
+                           user_log_mask=False, npratio=2, user_log_length=3, compute_dtype="bf16")
+    m = NAML.Model(args, F.load_title_table(d), 0, 0)
+    assert isinstance(m.news_encoder.title_embeddings, NAML.TitleTable)
+    sd = m.state_dict()
+    w = sd["news_encoder.title_embeddings.weight"]
+    assert w.dtype == torch.float32 and tuple(w.shape) == (rows, T * Dm) and np.array_equal(w.numpy(), emb)
+    assert all(p.requires_grad for p in m.parameters())            # the frozen table is no Parameter: nothing to exclude
+    m2 = NAML.Model(args, np.zeros_like(emb), 0, 0)
+    m2.load_state_dict(sd, strict=True)
+    assert np.array_equal(m2.state_dict()["news_encoder.title_embeddings.weight"].numpy(), emb)
+    sd.pop("news_encoder.title_embeddings.weight")
+    with pytest.raises(RuntimeError, match="title_embeddings.weight"):
+        m2.load_state_dict(sd, strict=True)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m.news_encoder.title_embeddings.packed(1)
+    args.freeze_embedding = False                                  # trainable: the reference's nn.Embedding, as before
+    assert isinstance(NAML.Model(args, emb, 0, 0).news_encoder.title_embeddings, torch.nn.Embedding)

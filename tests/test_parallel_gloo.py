@@ -105,7 +105,34 @@ def _rank_main(rank, world, port, tmp, q):
         adam_err = ""
     except RuntimeError as e:
         adam_err = str(e)
-    q.put((rank, len(losses), w.tolist(), n_samples, means.tolist(), w0.tolist(), g_local.tolist(), fb.grad.tolist(), adam_err))
+    # the SPLIT collective of the default mode at world > 1: a parameter of >= 2**20 elements is laid out last, its gradient
+    # is all-reduced early (async, from the backward's hook), everything in front of it by allreduce()
+    torch.manual_seed(9 + rank)
+    big = torch.nn.Sequential(torch.nn.Embedding(4096, 256), torch.nn.Linear(256, 3))
+    fb2 = P.FlatBucket(big, lr=1e-2)
+    table = big[0].weight
+    split = {"armed": hasattr(table, "_nr_grad_ready"), "big_off": fb2._big_off, "numel": fb2.numel}
+    ids = torch.arange(64).reshape(8, 8) * (rank + 3) % 4096
+    big(ids).mul(float(rank + 1)).sum().backward()
+    g2_local = fb2.grad.clone()
+    table._nr_grad_ready()                                    # what ops.MHSAFunction.backward does after the table-gradient kernel
+    try:
+        table._nr_grad_ready()
+        split["second"] = ""
+    except RuntimeError as e:
+        split["second"] = str(e)
+    fb2.allreduce()
+    g2_split = fb2.grad.clone()
+    fb2.grad.copy_(g2_local)
+    fb2.allreduce()                                           # no hook call this time: ONE all-reduce over the whole buffer
+    split["same"] = bool(torch.equal(g2_split, fb2.grad))
+    table._nr_grad_ready()                                    # an aborted step: zero_grad() must wait for and drop the early handle
+    fb2.zero_grad()
+    split["cleared"] = fb2._early_work is None and float(fb2.grad.abs().sum()) == 0.0
+    split["calls"] = fb2.early_calls                          # (the rejected second announcement is not counted)
+    nz = torch.nonzero(g2_local).flatten()
+    q.put((rank, len(losses), w.tolist(), n_samples, means.tolist(), w0.tolist(), g_local.tolist(), fb.grad.tolist(), adam_err,
+           split, (nz.tolist(), g2_local[nz].tolist()), (torch.nonzero(g2_split).flatten().tolist(), g2_split[torch.nonzero(g2_split).flatten()].tolist())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -127,7 +154,7 @@ def test_train_and_test_loops_as_two_gloo_ranks(tmp_path):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, n0, w_a, ns_a, means_a, w0_a, gl_a, g_a, err_a), (_, n1, w_b, ns_b, means_b, w0_b, gl_b, g_b, err_b) = res
+    (_, n0, w_a, ns_a, means_a, w0_a, gl_a, g_a, err_a, sp_a, l2_a, s2_a), (_, n1, w_b, ns_b, means_b, w0_b, gl_b, g_b, err_b, sp_b, l2_b, s2_b) = res
     # both ranks ran the agreed number of batches and hold identical parameters
     expect = min((s + args.batch_size - 1) // args.batch_size for s in sizes)
     assert n0 == n1 == expect
@@ -166,6 +193,20 @@ def test_train_and_test_loops_as_two_gloo_ranks(tmp_path):
     assert w0_a == w0_b
     assert np.allclose(np.array(g_a), np.array(gl_a) + np.array(gl_b)) and g_a == g_b
     assert "no CPU fallback" in err_a and "no CPU fallback" in err_b
+
+    # the split collective (early table all-reduce + the rest): armed on both ranks, the table laid out last, result = sum of
+    # the local gradients = what the single all-reduce gives; a second announcement before step() raises; zero_grad() clears
+    for sp in (sp_a, sp_b):
+        assert sp["armed"] and 0 < sp["big_off"] and sp["numel"] - sp["big_off"] >= 4096 * 256
+        assert "second backward" in sp["second"] and sp["same"] and sp["calls"] == 2 and sp["cleared"]
+    want = {}
+    for idx, val in (l2_a, l2_b):
+        for i, v in zip(idx, val):
+            want[i] = want.get(i, 0.0) + v
+    for idx, val in (s2_a, s2_b):
+        got = dict(zip(idx, val))
+        assert set(got) == {i for i, v in want.items() if v != 0.0}
+        assert all(abs(got[i] - want[i]) <= 1e-6 * max(1.0, abs(want[i])) for i in got)
 
 
 def test_agreed_batch_count_single_process_and_sharding():
