@@ -172,8 +172,15 @@ def price_kernel(label, avg_ms, struct, dtype):
         ge = 2 if "bf16" in label else 4
         epi = _dims(label, r"epi=(\d+)")
         epi = epi[0] if epi else 0
+        gap = _dims(label, r"gap=(\d+)")
+        gap = gap[0] if gap else 0
+        # gap > 0: the im2col-free conv operand -- row m is the K contiguous elements starting at buffer row m + m/gap of a
+        # [M + M/gap, K/3] buffer, so consecutive rows OVERLAP: the launch reads each buffer row once, K/3 columns per row
+        Ka = K // 3 if gap else K
         if name.startswith("gemm_tn"):
-            by = M * (N + K) * ge                                 # both operands are activations, the output is a weight gradient
+            by = M * (N + Ka) * ge                                # both operands are activations, the output is a weight gradient
+        elif gap:
+            by = M * (Ka + N) * ge
         elif epi == 2:
             by = M * K * ge + M * N * 4                           # + fp32 atomic rows (upper bound: before run merging)
         elif epi == 1:
@@ -222,16 +229,27 @@ def price_kernel(label, avg_ms, struct, dtype):
     return None
 
 
-def pmc_file():
+def pmc_file(workload=None):
+    """The newest committed PMC summary (profiles/*_hbm_traffic_pmc.json) -- and only if it was collected on THIS workload:
+    `workload` = (model, dtype, batch) must equal the file's step_total.{model,dtype,batch} (the passes profile the default
+    NRMS bf16 B=512 train step; NAML / eval / fp32 / dense lines get no PMC traffic from it)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc.json")))
-    return json.load(open(files[-1])) if files else None
+    if not files:
+        return None
+    pm = json.load(open(files[-1]))
+    pm["_source"] = os.path.relpath(files[-1], ROOT)
+    tot = pm.get("step_total") or {}
+    if workload is not None and (tot.get("model"), tot.get("dtype"), tot.get("batch")) != tuple(workload):
+        return None
+    return pm
 
 
-def pmc_traffic(label):
+def pmc_traffic(label, workload=None):
     """HBM bytes per launch of the kernel behind `label`, from the committed rocprofv3 PMC passes of this command
     (profiles/*_hbm_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, FETCH doubled as
-    MI355X_MICROARCH.md prescribes for 16-byte coalesced reads on gfx950).  None when no matching entry exists."""
-    pm = pmc_file()
+    MI355X_MICROARCH.md prescribes for 16-byte coalesced reads on gfx950).  None when no matching entry exists or the
+    file belongs to another workload."""
+    pm = pmc_file(workload)
     if pm is None:
         return None
     key = {"gemm_nt[": "gemm_nt_kernelIDF16bLi0ELi0", "gemm_nt_dma": "gemm_nt_dma_kernel", "gemm_nt_wreg": "gemm_nt_wreg_kernel", "gemm_tn2": "tn2::gemm_tn2_kernel", "gemm_tn3": "tn3::gemm_tn3_kernel",
@@ -248,13 +266,15 @@ def pmc_traffic(label):
     return None
 
 
-def roofline_of(prof, dtype, struct):
-    """The kernel with the largest total time in the timed region, priced."""
+def roofline_of(prof, dtype, struct, workload=None):
+    """The kernel with the largest total time in the timed region, priced.  workload = (model, dtype, batch) of a plain
+    train run (PMC traffic is attached only from a PMC file of that very workload), None otherwise."""
     if not prof:
         return None
     label, (cnt, ms) = max(prof.items(), key=lambda kv: kv[1][1])
     pr = price_kernel(label, ms / cnt, struct, dtype)
-    out = {"kernel": label, "avg_ms": round(ms / cnt, 4), "launches": cnt, "traffic": pmc_traffic(label)}
+    out = {"kernel": label, "avg_ms": round(ms / cnt, 4), "launches": cnt,
+           "traffic": pmc_traffic(label, workload) if workload is not None else None}
     if pr is None:
         out.update({"bound": "hbm", "achieved": None, "peak": PEAK_HBM, "unit": "GB/s", "frac": None})
         return out
@@ -272,12 +292,13 @@ def step_roofline(model_name, dtype, batch, ms_per_step, plain=True):
     peak = PEAK_MFMA_BF16 if dtype == "bf16" else PEAK_MFMA_F32
     out = {"bound": "mfma", "algorithmic_flops": fl, "achieved": round(fl / (ms_per_step / 1e3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s"}
     out["frac"] = round(out["achieved"] / peak, 4)
-    pm = pmc_file()
+    pm = pmc_file((model_name, dtype, batch))
     fused_min = 3.0 * FUSED_MIN_BYTES_PER_IMP_FWD[dtype] * batch
     out["fused_min_bytes"] = int(fused_min)
     tot = pm.get("step_total") if pm else None
-    if plain and tot and tot.get("model") == model_name and tot.get("dtype") == dtype and tot.get("batch") == batch:
+    if plain and tot:
         out["hbm_bytes_per_step_pmc"] = int(tot["bytes_per_step"])
+        out["hbm_bytes_source"] = pm["_source"] + " (committed rocprofv3 --pmc passes of this command; NOT measured in this run)"
         out["wasted_traffic_ratio"] = round(tot["bytes_per_step"] / fused_min, 2)
         out["hbm_frac_of_peak_at_measured_time"] = round(tot["bytes_per_step"] / (ms_per_step / 1e3) / 1e9 / PEAK_HBM, 4)
     return out
@@ -295,43 +316,56 @@ def physical_cores():
     return max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline(args, V, seed, B=512, budget_s=20.0):
+def cpu_baseline(args, V, seed, B=512, timed_steps=3):
     """The CPU oracle (oracle/nr_oracle.py, torch-CPU fp32) on the SAME workload: NRMS train step (fwd + bwd + Adam,
-    Bernoulli dropout masks drawn per step) at B = 512, threads = physical cores.  Bounded sample: one warm-up
-    step, then as many timed steps (1..5) as fit ~30 s."""
+    Bernoulli dropout masks drawn per step) at B = 512.  torch's intra-op pool oversubscribes on the many
+    small ops of this graph, so the thread count is swept first (one step at B = 128 per candidate, fastest kept), then one
+    warm-up and `timed_steps` timed steps at B = 512 (SURVEY §8d asks for 3 + 5; 1 + 3 keeps the default run within minutes
+    -- the `sample` string says what was run)."""
     from oracle import nr_oracle as O
     cores = physical_cores()
-    torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(seed)
     table = torch.randn(V, args.word_embedding_dim, generator=g) * 0.4
     table[0] = 0
     sd = O.init_state_dict("NRMS", args, table, seed=0)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     opt = torch.optim.Adam(params.values(), lr=1e-4)
-    hist, mask, cand, label = synth_batches(args, B, V, 1, seed + 1, "cpu")[0]
     T, N, p = args.num_words_title, args.news_dim, args.drop_rate
 
-    def step():
-        keep = {"cand_word": torch.bernoulli(torch.full((B * 5, T, 300), 1 - p)),
-                "cand_ctx": torch.bernoulli(torch.full((B * 5, T, N), 1 - p)),
-                "hist_word": torch.bernoulli(torch.full((B * 50, T, 300), 1 - p)),
-                "hist_ctx": torch.bernoulli(torch.full((B * 50, T, N), 1 - p))}
-        loss, _ = O.nrms_forward(hist, mask, cand, label, params, args, keep=keep)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
+    def make_step(b):
+        hist, mask, cand, label = synth_batches(args, b, V, 1, seed + 1, "cpu")[0]
 
+        def step():
+            keep = {"cand_word": torch.bernoulli(torch.full((b * 5, T, 300), 1 - p)),
+                    "cand_ctx": torch.bernoulli(torch.full((b * 5, T, N), 1 - p)),
+                    "hist_word": torch.bernoulli(torch.full((b * 50, T, 300), 1 - p)),
+                    "hist_ctx": torch.bernoulli(torch.full((b * 50, T, N), 1 - p))}
+            loss, _ = O.nrms_forward(hist, mask, cand, label, params, args, keep=keep)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        return step
+
+    small = make_step(128)
+    sweep = {}
+    for th in sorted({t for t in (16, 32, 64, 128) if t <= max(cores, 16)} | {min(cores, 128)}):
+        torch.set_num_threads(th)
+        t0 = time.perf_counter()
+        small()
+        sweep[th] = round(time.perf_counter() - t0, 2)
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
+    step = make_step(B)
     t0 = time.perf_counter()
     step()
     warm = time.perf_counter() - t0
-    n = max(1, min(5, int(budget_s / max(warm, 1e-3))))
     t0 = time.perf_counter()
-    for _ in range(n):
+    for _ in range(timed_steps):
         step()
     dt = time.perf_counter() - t0
-    return {"value": round(B * n / dt, 2), "unit": "impressions/s", "cores": cores, "kind": "port",
-            "sample": f"NRMS train step (fwd+bwd+Adam, dropout 0.2) at B={B}, {n} timed step(s) after 1 warm-up "
-                      f"({warm:.1f} s), torch-CPU fp32, {cores} threads (physical cores)"}
+    return {"value": round(B * timed_steps / dt, 2), "unit": "impressions/s", "cores": threads, "kind": "port",
+            "sample": f"NRMS train step (fwd+bwd+Adam, dropout 0.2) at B={B}: {timed_steps} timed steps after 1 warm-up ({warm:.1f} s), "
+                      f"torch-CPU fp32, {threads} threads = fastest of the sweep {sweep} (seconds per B=128 step; host has {cores} physical cores)"}
 
 
 def cpu_eval_baseline(args, V, n_news, n_imp, seed, budget_s=20.0):
@@ -390,7 +424,7 @@ class ArrayShard:
 
 
 # ----------------------------------------------------------------------------------------- eval workload
-def run_eval(a, args, device, rank, world, dist_on):
+def run_eval(a, args, device, rank, world, dist_on, steps=None, warmup=None, cpu=True):
     """BASELINE configs[4], one GPU's share: encode the news corpus once (sharded over the ranks + all_gather when N > 1),
     then score `--eval-impressions` impressions (candidates ~U[2,100]) and rank them, all on the device."""
     import numpy as np
@@ -421,6 +455,10 @@ def run_eval(a, args, device, rank, world, dist_on):
             dist.barrier()
         torch.cuda.synchronize()
 
+    a = SimpleNamespace(**vars(a))
+    a.steps, a.warmup = (steps or a.steps), (a.warmup if warmup is None else warmup)
+    nv_keep = None
+
     def one_pass():
         nv = TR.encode_news(model, comb, a.eval_batch, device, shard_over_ranks=dist_on)
         scores, sums = TR.score_shard(model, nv, sh, a.eval_batch, device)
@@ -446,7 +484,7 @@ def run_eval(a, args, device, rank, world, dist_on):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
-        return
+        return None
     sums = sums.cpu().tolist()
     struct = {"live_token_rows": float((comb != 0).mean()), "live_titles": 1.0, "needed_titles": 1.0, "needed_tiles": 1.0, "live_gradient_slabs": 1.0,
               "attention_bwd_sequences": 1.0}
@@ -460,9 +498,250 @@ def run_eval(a, args, device, rank, world, dist_on):
     out["roofline"] = roofline_of(prof, a.dtype, struct)
     if prof:
         out["kernel_ms_per_step"] = {k: round(ms / a.steps, 4) for k, (c, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1])[:10]}
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and cpu:
         out["cpu_baseline"] = cpu_eval_baseline(make_args("fp32"), a.vocab, a.eval_news, n, 7)
-    print(json.dumps(out))
+    del model, nv_keep
+    from newsrecommendation_amd import ops as _ops
+    _ops.projected_tables._c.clear()
+    _ops.table_cache.invalidate()
+    _ops.pack_cache.clear()
+    torch.cuda.empty_cache()
+    return out
+
+
+def _rss():
+    """(anonymous resident MB, peak resident MB) of this process, from /proc/self/status."""
+    anon = peak = None
+    try:
+        for line in open("/proc/self/status"):
+            if line.startswith("RssAnon:"):
+                anon = int(line.split()[1]) / 1024.0
+            elif line.startswith("VmHWM:"):
+                peak = int(line.split()[1]) / 1024.0
+    except OSError:
+        pass
+    return anon, peak
+
+
+def build_naml_from_disk(a, args, device):
+    """BASELINE configs[2] start-up through SURVEY §8 row f3: the [N+1, T*D] fp32 title matrix is written block by block as a
+    plain `.npy` (the inflate-once cache file of formats.read_news_embeddings), memory-mapped, and streamed by
+    NAML.TitleTable into the packed bf16 table on the device.  Returns (model, load statistics)."""
+    import numpy as np
+    import tempfile
+    from newsrecommendation_amd.model import NAML
+    rows, width = a.naml_news + 1, args.num_words_title * args.word_embedding_dim
+    tmp = tempfile.mkdtemp(prefix="nr_bench_")
+    path = os.path.join(tmp, "title_embeddings.bpemb.npy")
+    mm = np.lib.format.open_memmap(path, mode="w+", dtype=np.float32, shape=(rows, width))
+    g = torch.Generator().manual_seed(1)
+    for r0 in range(0, rows, 4096):
+        r1 = min(rows, r0 + 4096)
+        mm[r0:r1] = (torch.randn(r1 - r0, width, generator=g) * 0.4).numpy()
+    mm[0] = 0
+    mm.flush()
+    del mm
+    anon0, _ = _rss()
+    torch.cuda.synchronize()
+    dev0 = torch.cuda.memory_allocated()
+    t0 = time.perf_counter()
+    table = np.load(path, mmap_mode="r")
+    model = NAML.Model(args, table, 17, 264).to(device)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    anon1, peak = _rss()
+    stats = {"source": "memory-mapped .npy (formats.read_news_embeddings cache layout), streamed by NAML.TitleTable",
+             "file_GB": round(rows * width * 4 / 1e9, 2), "load_s": round(dt, 2),
+             "device_MB_after_load": round((torch.cuda.memory_allocated() - dev0) / 1e6, 1),
+             "host_anon_rss_growth_MB": None if anon0 is None else round(anon1 - anon0, 1), "host_peak_rss_MB": peak and round(peak, 1)}
+    return model, stats, tmp
+
+
+def run_train(a, device, rank, world, dist_on, model_name, dtype, dense=False, steps=None, warmup=None, plain_headline=True):
+    """One train workload: W untimed warm-up steps, exactly K timed steps between barrier + synchronize fences, MAX over
+    ranks.  Returns the JSON dict on rank 0 (None elsewhere)."""
+    import shutil
+    import torch.distributed as dist
+    from newsrecommendation_amd import _lib, ops as _ops, parallel, train as TR
+    from newsrecommendation_amd.model import NRMS
+    steps, warmup = (steps or a.steps), (a.warmup if warmup is None else warmup)
+    args = make_args(dtype)
+    args.freeze_embedding = bool(a.freeze_embedding)
+    args.compact_history = bool(a.compact_history)
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1)
+    table_load, tmpdir = None, None
+    if model_name == "NRMS":
+        table = torch.randn(a.vocab, args.word_embedding_dim, generator=g) * 0.4
+        table[0] = 0
+        model = NRMS.Model(args, table.numpy()).to(device)
+    else:
+        args.use_category = args.use_subcategory = True
+        args.freeze_embedding = True                      # src/demo.sh:12
+        model, table_load, tmpdir = build_naml_from_disk(a, args, device)
+    model.train()
+    if a.deterministic:
+        _ops.set_deterministic(True, elements=sum(p.numel() for p in model.parameters() if p.requires_grad) + (1 << 20), device=device)
+    net, bucket, opt = model, None, None
+    if a.dp_mode == "flat":
+        bucket = parallel.FlatBucket(model, lr=1e-4)       # rank-0 broadcast; per step ONE all-reduce + ONE fused Adam kernel
+    else:
+        # src/main.py:76 (defaults); fused=True is the same update rule in one multi-tensor kernel instead of ~6
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+        if dist_on:
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[device.index])   # src/main.py:82
+    if model_name == "NRMS":
+        batches = synth_batches(args, a.batch, a.vocab, 4, 100 + rank, device, dense=dense)
+    else:
+        batches = synth_batches_naml(args, a.batch, a.naml_news, 4, 100 + rank, device, dense=dense)
+
+    feed = None
+    if a.feed == "device":
+        if model_name != "NRMS":
+            raise SystemExit("--feed device is wired for NRMS inputs")
+        import numpy as np
+        n_news, n_lines = 65000, a.batch * (steps + warmup)
+        comb = synth_news_table(args, n_news, a.vocab, 3).numpy()
+        rnd = np.random.RandomState(100 + rank)
+        hl = np.full(n_lines, 50) if dense else rnd.randint(0, 51, n_lines)
+        hist = rnd.randint(1, n_news + 1, (n_lines, 50)).astype(np.int32)
+        mask = (np.arange(50)[None, :] >= (50 - hl)[:, None]).astype(np.float32)
+        hist[mask == 0] = 0
+        sh = ArrayShard(n_lines, hist=hist, mask=mask, pos=rnd.randint(1, n_news + 1, n_lines).astype(np.int32),
+                        neg=rnd.randint(1, n_news + 1, (n_lines, 4)).astype(np.int32), npratio=4)
+        feed = TR.DeviceFeed(sh, comb, a.batch, device)
+        feed.start_epoch()
+
+    def step(i):
+        hist, mask, cand, label = feed.batch(i) if feed is not None else batches[i % len(batches)]
+        loss, score = net(hist, mask, cand, label)
+        if opt is not None:
+            opt.zero_grad()
+        loss.backward()
+        if bucket is not None:
+            bucket.step()
+        else:
+            opt.step()
+        return loss
+
+    def fence():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # Per-kernel timing (HIP events inside the library).  A pair of event records costs ~3 us of stream time, and bracketing
+    # the dozen large launches of a step costs the timed region 2-3 %: so the WARM-UP steps (all but the first, which packs
+    # and allocates) are bracketed broadly -- that is where kernel_ms_per_step and the choice of the dominant kernel come
+    # from -- and the TIMED region brackets only that dominant kernel, which `roofline` is computed from.
+    # --all-kernels: every launch, in the timed region (a diagnostic run, not a headline number).
+    prof_on = (not a.no_prof) and rank == 0
+    warm_prof, dominant = {}, None
+    for i in range(warmup):
+        if prof_on and not a.all_kernels and i == 1:
+            torch.cuda.synchronize()
+            _lib.prof_enable(2)
+        loss = step(i)
+    if prof_on and not a.all_kernels and warmup >= 2:
+        _lib.prof_enable(False)
+        warm_prof = _lib.prof_collect()
+        if warm_prof:
+            dominant = max(warm_prof.items(), key=lambda kv: kv[1][1])[0]
+    fence()
+    if prof_on:
+        if a.all_kernels:
+            _lib.prof_enable(1)
+        elif dominant is not None:
+            _lib.prof_enable(3, only=dominant)
+        else:
+            _lib.prof_enable(2)                     # no warm-up to choose from: the launches over >= 65 536 rows
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = {}
+    if prof_on:
+        _lib.prof_enable(False)
+        prof = _lib.prof_collect()
+    if dist_on:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    out = None
+    if rank == 0:
+        total = a.batch * world * steps
+        ms_step = dt / steps * 1e3
+        if feed is not None:
+            batches = [feed.batch(i) for i in range(warmup, warmup + 4)]
+        struct = batch_structure(batches, args, model_name)
+        plain = plain_headline and not (dense or a.deterministic or a.compact_history)
+        out = {"metric": f"train impressions/sec @ batch {a.batch}, " + model_name, "value": round(total / dt, 1), "unit": "impressions/s",
+               "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(ms_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "config": {"workload": model_name + " train step (fwd+bwd+Adam), MIND-small shapes: title_len=30, history=50, "
+                                      "npratio=4, 300-d " + ("word table" if model_name == "NRMS" else "per-news title rows, 3 views")
+                                      + (", DENSE batch (no padding)" if dense else ""),
+                          "per_gpu_batch": a.batch, "global_batch": a.batch * world,
+                          **({"vocab_rows": a.vocab} if model_name == "NRMS" else {"title_table_rows": a.naml_news + 1, "table_load": table_load}),
+                          "dropout": args.drop_rate, "freeze_embedding": args.freeze_embedding,
+                          "compact_history": bool(a.compact_history), "dense_batch": bool(dense), "feed": a.feed,
+                          "deterministic": bool(a.deterministic),
+                          "optimizer": "flat bucket + HIP fused Adam" if bucket is not None else "DDP + torch.optim.Adam(fused)",
+                          "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "batch_structure": struct}}
+        if dist_on and a.dist_backend != "nccl":
+            out["config"]["rehearsal"] = f"{a.dist_backend} backend, ranks share GPUs: NOT a measurement"
+        # the committed PMC passes profile the default (sparse, resident, non-deterministic) workload only
+        out["roofline"] = roofline_of(prof, dtype, struct, workload=(model_name, dtype, a.batch) if plain else None)
+        if out["roofline"] is not None:
+            out["roofline"]["step"] = step_roofline(model_name, dtype, a.batch, ms_step, plain=plain)
+        # the per-kernel table: from the timed region when it was bracketed broadly, else from the warm-up steps (the
+        # dominant kernel's entry is then replaced by its timed-region measurement)
+        table, tsteps, src = (prof, steps, "timed region") if (a.all_kernels or not warm_prof) else (dict(warm_prof), warmup - 1, "warm-up steps")
+        if table:
+            if src == "warm-up steps" and prof:
+                for k, (c, ms) in prof.items():
+                    table[k] = (round(c * tsteps / steps), ms * tsteps / steps)
+            tot = sum(ms for _, ms in table.values())
+            top = sorted(table.items(), key=lambda kv: -kv[1][1])[:(None if a.all_kernels else 12)]
+            out["kernel_ms_per_step"] = {k: round(ms / tsteps, 4) for k, (c, ms) in top}
+            out["kernel_ms_per_step"]["_all_timed_libnrhip_kernels"] = round(tot / tsteps, 4)
+            out["kernel_ms_per_step"]["_measured_in"] = src + (" (dominant kernel: timed region)" if src == "warm-up steps" else "")
+            fr = {}
+            for k, (c, ms) in top:
+                pr = price_kernel(k, ms / max(c, 1), struct, dtype)
+                if pr is not None:
+                    fr[k] = {"bound": pr["bound"], "frac": round(pr["achieved"] / pr["peak"], 3)}
+            out["kernel_roofline_frac"] = fr
+    # leave the device as found: the next workload of this process builds its own model
+    if a.deterministic:
+        _ops.set_deterministic(False)
+    del model, net, bucket, opt, batches, feed
+    _ops.pack_cache.clear()
+    _ops.table_cache.invalidate()
+    torch.cuda.empty_cache()
+    if tmpdir:
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return out
+
+
+def brief(out):
+    """What an `also` entry keeps of a workload's line."""
+    if out is None:
+        return None
+    r = out.get("roofline") or {}
+    b = {"metric": out["metric"], "value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"], "steps": out["steps"],
+         "warmup": out["warmup"], "dtype": out["dtype"], "workload": out["config"]["workload"],
+         "dominant_kernel": {k: r.get(k) for k in ("kernel", "avg_ms", "bound", "achieved", "peak", "unit", "frac")}}
+    if "step" in r:
+        b["step_frac_of_mfma_peak"] = r["step"].get("frac")
+    for k in ("table_load", "mean_auc", "scored_impressions"):
+        if k in out["config"]:
+            b[k] = out["config"][k]
+    if "kernel_ms_per_step" in out:
+        b["kernel_ms_per_step_top5"] = dict(list(out["kernel_ms_per_step"].items())[:5])
+    return b
 
 
 def main():
@@ -497,6 +776,9 @@ def main():
     ap.add_argument("--eval-news", type=int, default=100000)
     ap.add_argument("--eval-impressions", type=int, default=125000, help="impressions per GPU (1M over 8 GPUs)")
     ap.add_argument("--eval-batch", type=int, default=2048)
+    ap.add_argument("--no-also", action="store_true",
+                    help="headline only: skip the other BASELINE configs (NAML, eval, dense batch, fp32) that the default 1-GPU "
+                         "run measures in the same process and attaches under `also`")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -517,167 +799,39 @@ def main():
         else:
             dist.init_process_group(a.dist_backend)
 
-    from newsrecommendation_amd import _lib, parallel, train as TR
-    from newsrecommendation_amd.model import NAML, NRMS
-
-    args = make_args(a.dtype)
     if a.eval:
         if a.steps == 20 and a.warmup == 5:
             a.steps, a.warmup = 3, 1
-        run_eval(a, args, device, rank, world, dist_on)
+        out = run_eval(a, make_args(a.dtype), device, rank, world, dist_on)
+        if out is not None:
+            print(json.dumps(out))
         if dist_on:
             dist.destroy_process_group()
         return
-    args.freeze_embedding = bool(a.freeze_embedding)
-    args.compact_history = bool(a.compact_history)
-    torch.manual_seed(0)
-    g = torch.Generator().manual_seed(1)
-    if a.model == "NRMS":
-        table = torch.randn(a.vocab, args.word_embedding_dim, generator=g) * 0.4
-        table[0] = 0
-        model = NRMS.Model(args, table.numpy()).to(device)
-    else:
-        args.use_category = args.use_subcategory = True
-        args.freeze_embedding = True                      # src/demo.sh:12
-        table = torch.randn(a.naml_news + 1, args.num_words_title * args.word_embedding_dim, generator=g) * 0.4
-        table[0] = 0
-        model = NAML.Model(args, table.numpy(), 17, 264).to(device)
-    model.train()
-    if a.deterministic:
-        from newsrecommendation_amd import ops as _ops
-        _ops.set_deterministic(True, elements=sum(p.numel() for p in model.parameters()) + (1 << 20), device=device)
-    net, bucket, opt = model, None, None
-    if a.dp_mode == "flat":
-        bucket = parallel.FlatBucket(model, lr=1e-4)       # rank-0 broadcast; per step ONE all-reduce + ONE fused Adam kernel
-    else:
-        # src/main.py:76 (defaults); fused=True is the same update rule in one multi-tensor kernel instead of ~6
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
-        if dist_on:
-            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index])   # src/main.py:82
-    if a.model == "NRMS":
-        batches = synth_batches(args, a.batch, a.vocab, 4, 100 + rank, device, dense=a.dense_batch)
-    else:
-        batches = synth_batches_naml(args, a.batch, a.naml_news, 4, 100 + rank, device, dense=a.dense_batch)
 
-    feed = None
-    if a.feed == "device":
-        if a.model != "NRMS":
-            raise SystemExit("--feed device is wired for NRMS inputs")
-        import numpy as np
-        n_news, n_lines = 65000, a.batch * (a.steps + a.warmup)
-        comb = synth_news_table(args, n_news, a.vocab, 3).numpy()
-        rnd = np.random.RandomState(100 + rank)
-        hl = np.full(n_lines, 50) if a.dense_batch else rnd.randint(0, 51, n_lines)
-        hist = rnd.randint(1, n_news + 1, (n_lines, 50)).astype(np.int32)
-        mask = (np.arange(50)[None, :] >= (50 - hl)[:, None]).astype(np.float32)
-        hist[mask == 0] = 0
-        sh = ArrayShard(n_lines, hist=hist, mask=mask, pos=rnd.randint(1, n_news + 1, n_lines).astype(np.int32),
-                        neg=rnd.randint(1, n_news + 1, (n_lines, 4)).astype(np.int32), npratio=4)
-        feed = TR.DeviceFeed(sh, comb, a.batch, device)
-        feed.start_epoch()
-
-    def step(i):
-        hist, mask, cand, label = feed.batch(i) if feed is not None else batches[i % len(batches)]
-        loss, score = net(hist, mask, cand, label)
-        if opt is not None:
-            opt.zero_grad()
-        loss.backward()
-        if bucket is not None:
-            bucket.step()
-        else:
-            opt.step()
-        return loss
-
-    def fence():
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # Per-kernel timing (HIP events inside the library).  A pair of event records costs ~3 us of stream time, and bracketing
-    # the dozen large launches of a step costs the timed region 2-3 %: so the WARM-UP steps (all but the first, which packs
-    # and allocates) are bracketed broadly -- that is where kernel_ms_per_step and the choice of the dominant kernel come
-    # from -- and the TIMED region brackets only that dominant kernel, which `roofline` is computed from.
-    # --all-kernels: every launch, in the timed region (a diagnostic run, not a headline number).
-    prof_on = (not a.no_prof) and rank == 0
-    warm_prof, dominant = {}, None
-    for i in range(a.warmup):
-        if prof_on and not a.all_kernels and i == 1:
-            torch.cuda.synchronize()
-            _lib.prof_enable(2)
-        loss = step(i)
-    if prof_on and not a.all_kernels and a.warmup >= 2:
-        _lib.prof_enable(False)
-        warm_prof = _lib.prof_collect()
-        if warm_prof:
-            dominant = max(warm_prof.items(), key=lambda kv: kv[1][1])[0]
-    fence()
-    if prof_on:
-        if a.all_kernels:
-            _lib.prof_enable(1)
-        elif dominant is not None:
-            _lib.prof_enable(3, only=dominant)
-        else:
-            _lib.prof_enable(2)                     # no warm-up to choose from: the launches over >= 65 536 rows
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss = step(a.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    prof = {}
-    if prof_on:
-        _lib.prof_enable(False)
-        prof = _lib.prof_collect()
-    if dist_on:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    final_loss = float(loss.item())
-
-    if rank == 0:
-        total = a.batch * world * a.steps
-        ms_step = dt / a.steps * 1e3
-        if feed is not None:
-            batches = [feed.batch(i) for i in range(a.warmup, a.warmup + 4)]
-        struct = batch_structure(batches, args, a.model)
-        out = {"metric": f"train impressions/sec @ batch {a.batch}, " + a.model, "value": round(total / dt, 1), "unit": "impressions/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": a.model + " train step (fwd+bwd+Adam), MIND-small shapes: title_len=30, history=50, "
-                                      "npratio=4, 300-d " + ("word table" if a.model == "NRMS" else "per-news title rows, 3 views")
-                                      + (", DENSE batch (no padding)" if a.dense_batch else ""),
-                          "per_gpu_batch": a.batch, "global_batch": a.batch * world, "vocab_rows": a.vocab,
-                          "dropout": args.drop_rate, "freeze_embedding": args.freeze_embedding,
-                          "compact_history": bool(a.compact_history), "dense_batch": bool(a.dense_batch), "feed": a.feed,
-                          "deterministic": bool(a.deterministic),
-                          "optimizer": "flat bucket + HIP fused Adam" if bucket is not None else "DDP + torch.optim.Adam(fused)",
-                          "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "batch_structure": struct}}
-        if dist_on and a.dist_backend != "nccl":
-            out["config"]["rehearsal"] = f"{a.dist_backend} backend, ranks share GPUs: NOT a measurement"
-        out["roofline"] = roofline_of(prof, a.dtype, struct)
-        if out["roofline"] is not None:
-            # the committed PMC passes profile the default (sparse, resident, non-deterministic) workload only
-            out["roofline"]["step"] = step_roofline(a.model, a.dtype, a.batch, ms_step,
-                                                    plain=not (a.dense_batch or a.deterministic or a.compact_history))
-        # the per-kernel table: from the timed region when it was bracketed broadly, else from the warm-up steps (the
-        # dominant kernel's entry is then replaced by its timed-region measurement)
-        table, tsteps, src = (prof, a.steps, "timed region") if (a.all_kernels or not warm_prof) else (dict(warm_prof), a.warmup - 1, "warm-up steps")
-        if table:
-            if src == "warm-up steps" and prof:
-                for k, (c, ms) in prof.items():
-                    table[k] = (round(c * tsteps / a.steps), ms * tsteps / a.steps)
-            tot = sum(ms for _, ms in table.values())
-            top = sorted(table.items(), key=lambda kv: -kv[1][1])[:(None if a.all_kernels else 12)]
-            out["kernel_ms_per_step"] = {k: round(ms / tsteps, 4) for k, (c, ms) in top}
-            out["kernel_ms_per_step"]["_all_timed_libnrhip_kernels"] = round(tot / tsteps, 4)
-            out["kernel_ms_per_step"]["_measured_in"] = src + (" (dominant kernel: timed region)" if src == "warm-up steps" else "")
-            fr = {}
-            for k, (c, ms) in top:
-                pr = price_kernel(k, ms / max(c, 1), struct, a.dtype)
-                if pr is not None:
-                    fr[k] = {"bound": pr["bound"], "frac": round(pr["achieved"] / pr["peak"], 3)}
-            out["kernel_roofline_frac"] = fr
-        if world == 1 and not a.no_cpu_baseline and a.model == "NRMS":
-            out["cpu_baseline"] = cpu_baseline(args, a.vocab, 7)
+    out = run_train(a, device, rank, world, dist_on, a.model, a.dtype, dense=a.dense_batch)
+    # The default 1-GPU run (the driver's BENCH line) also puts the other BASELINE configs on the same clock, in this
+    # process, after the headline's timed region: configs[2] NAML, configs[4] eval (one GPU's share), the dense batch (what
+    # the step costs when the sparsity shortcuts find nothing) and the fp32 mode (the one held to 1e-4).  Headline keys are
+    # untouched; each entry is a full measurement with its own warm-up, fences and dominant kernel.
+    headline_default = (a.model == "NRMS" and a.dtype == "bf16" and not a.dense_batch and not a.deterministic and a.feed == "resident"
+                        and not a.compact_history and a.dp_mode == "flat" and not a.freeze_embedding)
+    if out is not None and world == 1 and headline_default and not a.no_also:
+        also = {}
+        t_also = time.perf_counter()
+        for key, fn in (("naml", lambda: run_train(a, device, rank, world, False, "NAML", "bf16", steps=10, warmup=3)),
+                        ("eval", lambda: run_eval(a, make_args("bf16"), device, rank, world, False, steps=2, warmup=1, cpu=False)),
+                        ("dense", lambda: run_train(a, device, rank, world, False, "NRMS", "bf16", dense=True, steps=10, warmup=3)),
+                        ("fp32", lambda: run_train(a, device, rank, world, False, "NRMS", "fp32", steps=5, warmup=2))):
+            try:
+                also[key] = brief(fn())
+            except Exception as e:                      # the headline line must survive a failing side workload
+                also[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        also["_seconds"] = round(time.perf_counter() - t_also, 1)
+        out["also"] = also
+    if out is not None and world == 1 and not a.no_cpu_baseline and a.model == "NRMS":
+        out["cpu_baseline"] = cpu_baseline(make_args(a.dtype), a.vocab, 7)
+    if out is not None:
         print(json.dumps(out))
     if dist_on:
         dist.destroy_process_group()

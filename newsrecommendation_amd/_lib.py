@@ -14,7 +14,8 @@ NR_F32, NR_BF16 = 0, 1
 NR_SRC_DENSE, NR_SRC_GATHER = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnrhip.so")
+# NRHIP_LIB: another build of the same library (same-box A/B measurements of kernel variants, tools/ab.sh); default in-tree
+LIB_PATH = os.environ.get("NRHIP_LIB") or os.path.join(_HERE, "libnrhip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 c_f32p = C.POINTER(C.c_float)

@@ -435,6 +435,13 @@ __global__ __launch_bounds__(AW * 64) void attn_mfma_bwd_kernel(AttnMArgs a) {
 // ==========================================================================================
 namespace b16 {
 constexpr int IMG = 32 * 32;
+// Panel kernels (L <= 32): the AW head images of a group used to sit a whole number of KB apart, so the 8-byte pieces of a
+// panel row (4 heads x d/4 pieces, scattered by one ds_write_b64 per 16 lanes) met on the same banks -- 3-4 way conflicts,
+// 41-50 % of the LDS-active cycles (profiles/r02_final_sq_counters.txt).  Every head slot now carries HPAD elements of slack
+// and starts hbank(h) elements into it: 0 / 64 / 32 / 96 bytes modulo the 128-byte bank window, the best a 16-byte granule
+// allows (the b128 fragment reads need that alignment): model 153 -> 96 LDS cycles per 12 piece writes (48 = conflict free).
+constexpr int HPAD = 64;
+__device__ __forceinline__ constexpr int hbank(int h) { return 16 * (((h & 1) << 1) | ((h >> 1) & 1)); }
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 __device__ __forceinline__ int ioff(int row, int col) { return row * 32 + ((((col >> 3) ^ ((row >> 2) & 3)) << 3) | (col & 7)); }
@@ -627,7 +634,7 @@ template <int PT, bool FULL = false> __device__ __forceinline__ Pieces<PT> make_
     const int h = (int)(((uint32_t)q * inv_pph) >> 16), c = 4 * (q - h * pph);
     const bool ok = row < L;
     pc.rh[t] = (row & 31) | ((ok ? h : AW) << 8);     // head slot AW = never active
-    pc.lq[t] = (h * nimg * IMG + ioff(row & 31, c)) | ((4 * q) << 16);
+    pc.lq[t] = (h * (nimg * IMG + HPAD) + hbank(h) + ioff(row & 31, c)) | ((4 * q) << 16);
   }
   return pc;
 }
@@ -720,8 +727,8 @@ __device__ __forceinline__ void panel_put_bias(bf16_t* img0, const Pieces<PT>& p
     }
   }
 }
-__device__ __forceinline__ void zero_images(bf16_t* imgs, int count, int tid) {
-  for (int i = tid; i < count * IMG / 8; i += AW * 64) reinterpret_cast<uint4*>(imgs)[i] = make_uint4(0, 0, 0, 0);
+__device__ __forceinline__ void zero_images(bf16_t* imgs, int elems, int tid) {      // elems: a multiple of 8
+  for (int i = tid; i < elems / 8; i += AW * 64) reinterpret_cast<uint4*>(imgs)[i] = make_uint4(0, 0, 0, 0);
 }
 
 // Outputs leave the same way they came: each wave drops its head's [L, d] result (lane = token, registers = 4-column
@@ -768,18 +775,19 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR address math
   bf16_t* img0 = reinterpret_cast<bf16_t*>(smem);
-  bf16_t* base = img0 + (size_t)wid * 3 * IMG;
+  constexpr int HS = 3 * IMG + HPAD;                     // head slot: Q | K | V images + bank-offset slack (see hbank)
+  bf16_t* base = img0 + (size_t)wid * HS + hbank(wid);
   bf16_t *sQ = base, *sK = base + IMG, *sV = base + 2 * IMG;
-  float* sMask = reinterpret_cast<float*>(img0 + (size_t)AW * 3 * IMG) + wid * 32;
-  bf16_t* sOut = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(img0 + (size_t)AW * 3 * IMG) + AW * 32);   // [32][ops]
+  float* sMask = reinterpret_cast<float*>(img0 + (size_t)AW * HS) + wid * 32;
+  bf16_t* sOut = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(img0 + (size_t)AW * HS) + AW * 32);   // [32][ops]
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
   bf16_t* y = reinterpret_cast<bf16_t*>(a.y);
   const int L = LC ? LC : a.L, d = DC ? DC : a.d, heads = HC ? HC : a.heads;
-  const int N = heads * d, N3 = 3 * N, ops = AW * d + 8;
+  const int N = heads * d, N3 = 3 * N, ops = AW * d + 4;     // ops / 4 odd (d even): the 8-byte row writes of 16 lanes hit 16 distinct slots
   const int h2 = lane >> 5;
   const float c1 = a.scale * LOG2E;   // scale > 0: the row maximum can be taken on the raw scores
   const Pieces<PT> pc = make_pieces<PT, FULL>(tid, L, d, 3);
-  zero_images(img0, AW * 3, tid);
+  zero_images(img0, AW * HS, tid);
   bf16_t* sBias = sOut + 32 * ops;                     // SUB: bias [3N] as bf16 (what the projection of a zero row is)
   if (SUB)
     for (int i = tid; i < N3; i += AW * 64) sBias[i] = (bf16_t)a.bias[i];
@@ -935,9 +943,11 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
   // product that contracts over the padded head dimension pairs a dirty operand with a clean one (K.Q^T, V.G^T), while
   // the token-contracting products meet exact zeros of P / dS / G in the padded rows.
   bf16_t* img0 = reinterpret_cast<bf16_t*>(smem);
-  bf16_t *imQ = img0, *imV = img0 + AW * IMG, *imK = img0 + 2 * AW * IMG, *imG = img0 + 3 * AW * IMG;
-  bf16_t *sQ = imQ + wid * IMG, *sK = imK + wid * IMG, *sV = imV + wid * IMG, *sG = imG + wid * IMG;
-  float* sF = reinterpret_cast<float*>(img0 + (size_t)AW * 4 * IMG) + wid * 128;
+  constexpr int HS = IMG + HPAD, MS = AW * HS;            // head slot (image + bank-offset slack, see hoff) / matrix block
+  bf16_t *imQ = img0, *imV = img0 + MS, *imK = img0 + 2 * MS, *imG = img0 + 3 * MS;
+  const int wo = wid * HS + hbank(wid);
+  bf16_t *sQ = imQ + wo, *sK = imK + wo, *sV = imV + wo, *sG = imG + wo;
+  float* sF = reinterpret_cast<float*>(img0 + (size_t)4 * MS) + wid * 128;
   float *sMask = sF, *sM = sF + 32, *sInv = sF + 64, *sRd = sF + 96;
   const int L = LC ? LC : a.L, d = DC ? DC : a.d, heads = HC ? HC : a.heads;
   const int N = heads * d, N3 = 3 * N;
@@ -947,8 +957,8 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
   const int h2 = lane >> 5, li = lane & 31;
   const float c1 = a.scale * LOG2E;
   const Pieces<PT> pc = make_pieces<PT, FULL>(tid, L, d, 1);    // per matrix the AW head images are adjacent
-  zero_images(img0, AW * 4, tid);
-  bf16_t* sBias = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(img0 + (size_t)AW * 4 * IMG) + AW * 128);   // SUB: bias [3N] as bf16
+  zero_images(img0, 4 * MS, tid);
+  bf16_t* sBias = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(img0 + (size_t)4 * MS) + AW * 128);   // SUB: bias [3N] as bf16
   if (SUB)
     for (int i = tid; i < N3; i += AW * 64) sBias[i] = (bf16_t)a.bias[i];
 
@@ -1106,9 +1116,11 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     // stored straight from the registers: routing dQ/dK/dV through LDS panels like the forward output measured
     // slower here (1.38 vs 1.18 ms)
     if (FULL || 3 * 32 * AW * d <= 2 * AW * IMG) {        // d <= 21 (FULL is only launched for such shapes)
-      // dQ|dK|dV leave through three [32][AW*d] panels that ALIAS the (now dead) Q and V images: the workgroup then
-      // stores consecutive 8-byte pieces, 160-byte runs per row and matrix instead of 40-byte head slivers
-      const int ops = AW * d;
+      // dQ|dK|dV leave through three [32][AW*d + 4] panels that ALIAS the (now dead) Q and V images: the workgroup then
+      // stores consecutive 8-byte pieces, 160-byte runs per row and matrix instead of 40-byte head slivers.  Row stride
+      // AW*d + 4: an odd number of 8-byte slots, so the 16 lanes of a write group hit 16 distinct slots (AW*d = 80 gave
+      // 4-way conflicts); 3 * 32 * (AW*d + 4) <= 2 * MS holds for every d this branch admits.
+      const int ops = AW * d + 4;
       __syncthreads();                                   // every wave is done reading the images
       acc_t_to_panel<false>(dq, img0, ops, wid, Ls, d, lane, nodrop, 0, 0);
       acc_t_to_panel<false>(dk, img0 + 32 * ops, ops, wid, Ls, d, lane, nodrop, 0, 0);
@@ -1619,9 +1631,9 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
     NR_CHECK_LAUNCH();
     return NR_OK;
   }
-  const size_t panel = (size_t)32 * (AW * a.d + 8) * sizeof(bf16_t);
-  const size_t smem = bwd ? AW * (4 * IMG * sizeof(bf16_t) + 128 * sizeof(float))
-                          : AW * (3 * IMG * sizeof(bf16_t) + 32 * sizeof(float)) + panel;
+  const size_t panel = (size_t)32 * (AW * a.d + 4) * sizeof(bf16_t);
+  const size_t smem = bwd ? AW * (4 * (IMG + HPAD) * sizeof(bf16_t) + 128 * sizeof(float))
+                          : AW * ((3 * IMG + HPAD) * sizeof(bf16_t) + 32 * sizeof(float)) + panel;
   const bool p3 = a.L * a.d <= 768, sub = a.tmask != nullptr;
   const size_t smem_s = smem + (sub ? (size_t)3 * a.N * sizeof(bf16_t) : 0);
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(AW * 64), smem_s, stream, a); };

@@ -2592,9 +2592,10 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
                          : launch_nt_wreg_m<EPI_POOLBWD, 4, 7, 2, WREG_DENSE>(A, B, ldb, M, N, K, ep, stream);
       }
     }
-    NrProfScope ps(stream, ep.row_count ? "gemm_nt_dma_live[bf16,epi=%d,Mmax=%d,N=%d,K=%d]"
-                                        : (tile_skip ? "gemm_nt_dma_needed[bf16,epi=%d,Mmax=%d,N=%d,K=%d]" : "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d]"),
-                   epi, M, N, K);
+    // (gap=T: the operand's rows overlap -- the conv's im2col-free operand, K/3 fresh columns per row: bench.py prices its bytes so)
+    NrProfScope ps(stream, ep.row_count ? "gemm_nt_dma_live[bf16,epi=%d,Mmax=%d,N=%d,K=%d,gap=%d]"
+                                        : (tile_skip ? "gemm_nt_dma_needed[bf16,epi=%d,Mmax=%d,N=%d,K=%d,gap=%d]" : "gemm_nt_dma[bf16,epi=%d,M=%d,N=%d,K=%d,gap=%d]"),
+                   epi, M, N, K, A.gap);
     const int c13 = ((N + 207) / 208) * 13, c20 = ((N + 319) / 320) * 20;   // fewer padded column tiles wins
     if (c13 < c20) return launch_nt_dma_e<13>(A, B, ldb, M, N, K, epi, ep, stream);
     return launch_nt_dma_e<20>(A, B, ldb, M, N, K, epi, ep, stream);
@@ -2902,7 +2903,7 @@ int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream) {
 int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K,
                             int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream, int xgap) {
   NR_CHECK_ARG(tn3::eligible(ldc, ldx, M, N, K), "gemm_tn_slabs: shape not eligible");
-  NrProfScope ps(stream, "gemm_tn3_live[bf16,Mmax=%d,N=%d,K=%d]", M, N, K);
+  NrProfScope ps(stream, "gemm_tn3_live[bf16,Mmax=%d,N=%d,K=%d,gap=%d]", M, N, K, xgap);
   return tn3::launch(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap);
 }
 bool nr_gemm_tn_slabs_ok(int ldc, int ldx, int M, int N, int K) { return tn3::eligible(ldc, ldx, M, N, K); }
@@ -2917,7 +2918,7 @@ int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float
   const bool tn_v1 = nr_opt(NR_OPT_TN_V1) != 0;
   if (!tn_v1 && dtype == NR_BF16 && A.kind == ROWS_DENSE && A.drop.thresh == 0) {
     if (tn3::eligible(ldc, A.ld, M, N, K)) {
-      NrProfScope ps(stream, "gemm_tn3[bf16,M=%d,N=%d,K=%d]", M, N, K);
+      NrProfScope ps(stream, "gemm_tn3[bf16,M=%d,N=%d,K=%d,gap=%d]", M, N, K, A.gap);
       return tn3::launch(dC, ldc, A.base, A.ld, dW, ldw, db, M, N, K, Nstore, Kstore, stream, nullptr, nullptr, A.gap);
     }
     if (A.gap == 0) {                              // (gapped rows: the generic kernel below follows RowSrc::gap)

@@ -28,7 +28,7 @@ class TitleTable(nn.Module):
 
     def __init__(self, source, D, compute_dtype):
         super().__init__()
-        if source.ndim != 2 or source.shape[1] % int(D):
+        if len(source.shape) != 2 or source.shape[1] % int(D):
             raise ValueError(f"title table must be [rows, T*{D}], got {tuple(source.shape)}")
         self.source, self.D, self.compute_dtype = source, int(D), compute_dtype
         self.rows, self.T = int(source.shape[0]), int(source.shape[1]) // int(D)

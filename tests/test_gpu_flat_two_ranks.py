@@ -10,7 +10,8 @@ dropout on, B = 16 per rank, 3 steps.  Checked:
   * the early hook fired exactly once per backward (`FlatBucket.early_calls`), the table sits last in the bucket;
   * a single-process replay -- rank-0 initial weights, per step the two ranks' batches with each rank's own dropout
     seeds, gradients averaged, `nr_adam_step` with grad_scale 1 -- ends at the same parameters (<= 1e-5 * max|param|:
-    only the order of the fp32 atomics differs) and sees the same per-step losses;
+    only the order of the fp32 atomics differs; the two biases whose gradient is analytically zero are left out, Adam turns
+    their rounding noise into +-lr steps) and sees the same per-step losses;
   * a second backward before `step()` raises, and `zero_grad()` clears the pending early all-reduce."""
 import json
 import os
@@ -104,6 +105,7 @@ except RuntimeError as e:
     out["second"] = str(e)
 fb.zero_grad()
 out["cleared"] = fb._early_work is None
+out["early_calls_after"] = fb.early_calls      # the accepted extra backward counts, the rejected one does not
 torch.cuda.synchronize()
 dist.barrier()
 print("RESULT " + json.dumps(out))
@@ -147,7 +149,7 @@ def test_flat_bucket_two_ranks_equal_a_single_process_replay(tmp_path):
     # the split collective was armed and ran once per backward on both ranks; both hold the same parameters, bit for bit
     for o in outs:
         assert o["table_last"] and o["big_off"] is not None and o["numel"] - o["big_off"] >= V * 300
-        assert o["early_calls"] == STEPS + 1 and o["t"] == STEPS and len(o["losses"]) == STEPS
+        assert o["early_calls"] == STEPS and o["early_calls_after"] == STEPS + 1 and o["t"] == STEPS and len(o["losses"]) == STEPS
         assert "second backward" in o["second"] and o["cleared"]
     assert torch.equal(r0["param"], r1["param"])
     assert all(torch.equal(r0["sd"][k], r1["sd"][k]) for k in r0["sd"])
@@ -185,6 +187,12 @@ def test_flat_bucket_two_ranks_equal_a_single_process_replay(tmp_path):
     want, got = fb.param.cpu(), r0["param"]
     assert want.shape == got.shape
     tol = 1e-5 * float(want.abs().max())
-    err = float((want - got).abs().max())
-    assert err <= tol, (err, tol)
+    worst = {}
+    for name, p in model.named_parameters():
+        if name.endswith(("W_K.bias", "att_fc2.bias")):
+            # analytically zero gradients (a constant shift of all keys / of all pooling logits changes nothing): what is left
+            # is rounding noise, which Adam normalises to steps of +-lr -- not comparable between two runs of ANY optimizer
+            continue
+        worst[name] = float((p.detach().cpu() - r0["sd"][name]).abs().max())
+    assert len(worst) == 22 and max(worst.values()) <= tol, (sorted(worst.items(), key=lambda kv: -kv[1])[:4], tol)
     assert float((want - init).abs().max()) >= 0.5 * args.lr          # (and the three steps did move the parameters)

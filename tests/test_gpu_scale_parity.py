@@ -49,10 +49,9 @@ def _grad_report(model, oracle_grads, atol, rtol):
     return worst
 
 
-def _nrms_case(dt, seed):
+def _nrms_case(dt, seed, B=B, V=5000):
     cfg = O.default_cfg()
     g = torch.Generator().manual_seed(seed)
-    V = 5000
     table = torch.randn(V, cfg.word_embedding_dim, generator=g) * 0.4
     table[0] = 0
     sd = O.init_state_dict("NRMS", cfg, table, seed=seed + 1)
@@ -71,9 +70,13 @@ def _nrms_case(dt, seed):
 TOL = {"fp32": dict(tol=1e-4, gatol=1e-6, grtol=2e-4), "bf16": dict(tol=3e-2, gatol=3e-4, grtol=3e-2)}
 
 
-@pytest.mark.parametrize("dt,train", [("bf16", False), ("bf16", True), ("fp32", False)])
-def test_nrms_b128_every_gradient_against_the_oracle(dt, train):
-    cfg, sd, m, (hist, mask, cand, label) = _nrms_case(dt, 40)
+# every size-gated kernel of the benchmarked bf16 step (round-1 and round-2 paths alike): the launch log must show them
+STEP_KERNELS = ("gemm_tn3_live", "attn_mfma_bwd_live", "gemm_nt_dma_live", "attn_mfma_fwd_live", "needed_list", "pool_core_bwd",
+                "gemm_nt_wreg_live", "gemm_nt_wreg_needed", "rows_materialize_needed", "sort_rows_by_id")
+
+
+def _nrms_against_the_oracle(dt, train, B, V, seed):
+    cfg, sd, m, (hist, mask, cand, label) = _nrms_case(dt, seed, B, V)
     t = TOL[dt]
     m.train(train)
     keep = None
@@ -94,7 +97,7 @@ def test_nrms_b128_every_gradient_against_the_oracle(dt, train):
         ops.POISON_WORKSPACES = False
     if dt == "bf16":
         # the kernels of the benchmarked step, not their small-shape stand-ins
-        for want in ("gemm_tn3_live", "attn_mfma_bwd_live", "gemm_nt_dma_live", "attn_mfma_fwd_live", "needed_list", "pool_core_bwd"):
+        for want in STEP_KERNELS:
             assert _has(labels, want), (want, sorted(labels))
     if train:
         n, T, D, N, p = B * 55, cfg.num_words_title, cfg.word_embedding_dim, cfg.news_dim, cfg.drop_rate
@@ -113,6 +116,21 @@ def test_nrms_b128_every_gradient_against_the_oracle(dt, train):
           + ", ".join(f"{k.split('.', 1)[1]}={v:.2e}" for k, v in sorted(worst.items(), key=lambda kv: -kv[1])[:5]))
     tab = dict(m.named_parameters())["news_encoder.embedding_matrix.weight"]
     assert float(tab.grad[0].abs().max()) == 0.0                          # padding_idx row
+    return labels
+
+
+@pytest.mark.parametrize("dt,train", [("bf16", False), ("bf16", True), ("fp32", False)])
+def test_nrms_b128_every_gradient_against_the_oracle(dt, train):
+    _nrms_against_the_oracle(dt, train, B, 5000, 40)
+
+
+def test_nrms_b512_benched_shape_every_gradient_against_the_oracle():
+    """THE benchmarked configuration itself, once: B = 512 (M = 844 800 token rows, 28 160 titles), bf16, training mode with
+    the kernels' dropout draws exported to the oracle, a 30 000-row trainable word table (bench.py's workload), poisoned
+    workspaces.  Grid-dependent logic -- 8 XCD x persistent-workgroup block lists, whole-chip slab flags, the one-workgroup
+    list / scan kernels, the id sort over 275 k live rows -- runs here at the size the bench line is quoted on.  Loss, all
+    2 560 scores and EVERY gradient (incl. the full [30 000, 300] table gradient) against the CPU oracle; ~40 s of oracle."""
+    _nrms_against_the_oracle("bf16", True, 512, 30000, 60)
 
 
 @pytest.mark.parametrize("dt,train", [("bf16", True), ("fp32", False)])
