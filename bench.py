@@ -114,7 +114,7 @@ def batch_structure(batches, args, model_name):
     share of token rows with a non-padding id (`*_live` NT GEMMs), share of 32-row slabs that touch a title with a
     non-zero upstream gradient (`gemm_tn3_live`), share of sequences the attention backward walks."""
     T = args.num_words_title
-    live_rows, live_slabs, live_seq, live_titles, needed, needed_tiles = [], [], [], [], [], []
+    live_rows, live_slabs, live_seq, live_titles, needed, needed_tiles, walked = [], [], [], [], [], [], []
     for hist, mask, cand, _ in batches:
         B, H = mask.shape
         C = cand.shape[1]
@@ -137,10 +137,12 @@ def batch_structure(batches, args, model_name):
         needed_tiles.append(float(tile_nz.mean()))
         near = torch.nn.functional.max_pool1d(nz_title[None, None], kernel_size=7, stride=1, padding=3)[0, 0] > 0
         live_seq.append(float((~(allpad & ~near)).float().mean()))
+        walked.append(float((~(allpad & (nz_title == 0))).float().mean()))      # compact row storage: reach 0
     avg = lambda x: sum(x) / len(x)
     return {"live_token_rows": round(avg(live_rows), 4), "live_titles": round(avg(live_titles), 4), "needed_titles": round(avg(needed), 4),
             "needed_tiles": round(avg(needed_tiles), 4),
-            "live_gradient_slabs": round(avg(live_slabs), 4), "attention_bwd_sequences": round(avg(live_seq), 4)}
+            "live_gradient_slabs": round(avg(live_slabs), 4), "attention_bwd_sequences": round(avg(live_seq), 4),
+            "attention_bwd_sequences_compact": round(avg(walked), 4)}
 
 
 def _dims(label, pat):
@@ -159,7 +161,9 @@ def price_kernel(label, avg_ms, struct, dtype):
         if d is None:
             return None
         M, N, K = d
-        if name.endswith("_live"):
+        if name.endswith("_rows"):
+            M = M * struct["live_token_rows"]                    # dense over the compactly stored live rows
+        elif name.endswith("_live"):
             M = M * (struct["live_gradient_slabs"] if name.startswith("gemm_tn") else struct["live_token_rows"])
         elif name.endswith("_needed"):
             # row tiles (128 rows) / 32-row blocks (weights-in-registers kernels) with at least one needed title
@@ -201,6 +205,9 @@ def price_kernel(label, avg_ms, struct, dtype):
             by = rows * (304 + N) * esz
         elif "gather" in name:
             by = rows * (3 * N + N) * esz                        # gather projected Q|K|V rows (L2 / MALL), write y
+        elif name.startswith("attn_mfma_bwd_rows"):
+            # compact row storage: dy of every sequence walked; Q|K|V read and dQ|dK|dV written for the LIVE rows only
+            by = rows * (N * struct.get("attention_bwd_sequences_compact", 1.0) + 6 * N * struct["live_token_rows"]) * esz
         elif "fwd" in name:
             # read Q|K|V of the titles that have any live token (all-padding titles substitute the bias); write y of all
             # titles, or ("_live": the kernel walks the needed titles, a store-only kernel zero-fills the rest) of the needed ones
@@ -222,7 +229,9 @@ def price_kernel(label, avg_ms, struct, dtype):
         return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}
     if name.startswith("rows_materialize"):
         M, K = _dims(label, r"M(?:max)?=(\d+),K=(\d+)")
-        if name.endswith("_needed"):
+        if name.endswith("_live"):
+            M = M * struct["live_token_rows"]                    # only the live rows are written
+        elif name.endswith("_needed"):
             M = M * struct.get("needed_tiles", 1.0)              # titles near a needed one (upper bound: tile granularity)
         by = M * K * esz
         return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}

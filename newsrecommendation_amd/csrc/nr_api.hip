@@ -13,6 +13,10 @@ int nr_launch_attn(bool bwd, int dtype, const void* qkv, const float* mask, void
                    const int32_t* needed = nullptr);
 bool nr_attn_pad_ok(int dtype, int L, int d_head, const void* p0, const void* p1);
 bool nr_attn_rowsub_ok(int dtype, int L, int d_head, int heads);
+bool nr_attn_compact_ok(int dtype, int L, int d_head, int heads);
+int nr_launch_attn_bwd_compact(const void* qkv, const float* mask, const void* dy, void* dqkv, int n, int L, int heads, int d_head,
+                               const DropCfg& drop, hipStream_t stream, const uint32_t* tmask, const float* bias, const int32_t* seq_list,
+                               const int32_t* seq_count, const int32_t* pos, void* dump, float* db);
 int nr_launch_attn_gather_fwd(const void* proj_table, const int32_t* ids, const float* mask, void* y, int n, int L, int heads,
                               int d_head, const DropCfg& drop, hipStream_t stream);
 int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
@@ -42,7 +46,7 @@ struct OptDef { const char* name; int def; };
 const OptDef g_opt_defs[NR_OPT_COUNT] = {
     {"NO_SLABS", 0},   {"NO_ATTN_SKIP", 0}, {"SIDE_STREAM", 0}, {"ATTN_OLD", 0},  {"ATTN_VALU", 0},   {"NO_PAD_SUB", 0},
     {"NO_FUSED_FWD", 0}, {"NO_TN3", 0},     {"TN_V1", 0},       {"TN3_ROUNDS", 0}, {"TN3_WK", 0},      {"TN3_NI", 0},
-    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}, {"NO_ROW_SUB", 0}, {"ATTN_BWD_OCC4", 0}, {"NT_ABLATE", 0}, {"NT_WREG", 1}, {"NO_SCATTER_SORT", 0}, {"TN3_MIN_M", 16384}};
+    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}, {"NO_ROW_SUB", 0}, {"ATTN_BWD_OCC4", 0}, {"NT_ABLATE", 0}, {"NT_WREG", 1}, {"NO_SCATTER_SORT", 0}, {"TN3_MIN_M", 16384}, {"NO_COMPACT_ROWS", 0}};
 std::atomic<int> g_opt[NR_OPT_COUNT];
 std::once_flag g_opt_once;
 void opt_init() {
@@ -281,7 +285,7 @@ static int mhsa_rows(const nr_mhsa_desc* d, RowSrc* out) {
 // row_ws (int32): [0,4) counters | M live rows | M their ids | M padding rows | n per-sequence live-token masks |
 //                 slab scratch: n title flags, 4 counters, M/32 slab ids, 4 pad | sequence list: 4 counters, n entries
 struct MhsaWs {
-  size_t live_idx, live_ids, dead_idx, tmask, slab, seq, sort_idx, sort_ids, hist, total;   // offsets in int32 elements
+  size_t live_idx, live_ids, dead_idx, tmask, slab, seq, sort_idx, sort_ids, hist, pos, sort_k, dump, total;   // offsets in int32 elements
 };
 // table_rows > 0 (gather source): room for the live rows sorted by token id (table-gradient scatter) and its histogram
 static MhsaWs mhsa_ws_layout(int n, int L, int table_rows) {
@@ -293,7 +297,12 @@ static MhsaWs mhsa_ws_layout(int n, int L, int table_rows) {
   w.sort_idx = (w.seq + 4 + n + 4 + 3) / 4 * 4;                      // 16-byte aligned: the GEMM stages these lists by DMA
   w.sort_ids = w.sort_idx + (table_rows > 0 ? (M + 3) / 4 * 4 : 0);
   w.hist = w.sort_ids + (table_rows > 0 ? (M + 3) / 4 * 4 : 0);
-  w.total = w.hist + (table_rows > 0 ? (size_t)table_rows + 8 : 0);
+  // compact row storage (gather source): position of every row in the live list | the id-sorted rows' positions in it | one
+  // dump row of 3N <= 2048 elements (what an all-padding sequence's gradient stores hit)
+  w.pos = (w.hist + (table_rows > 0 ? (size_t)table_rows + 8 : 0) + 3) / 4 * 4;
+  w.sort_k = w.pos + (table_rows > 0 ? (M + 3) / 4 * 4 : 0);
+  w.dump = w.sort_k + (table_rows > 0 ? (M + 3) / 4 * 4 : 0);
+  w.total = w.dump + (table_rows > 0 ? 1024 : 0);
   return w;
 }
 // bwd_ws of the convolution (int32): n title flags | 4 counters | M/32 slab ids | pad
@@ -314,6 +323,20 @@ static bool conv_slab_shape(const nr_conv_desc* d) {
   const int M = d->n * d->T;
   return !nr_opt(NR_OPT_NO_SLABS) && d->dtype == NR_BF16 && d->x_rows != nullptr && M % 32 == 0 && d->T <= 32 && d->N % 8 == 0 &&
          nr_gemm_tn_slabs_ok(d->N, d->ld_rows, M, d->N, 3 * d->Dp);
+}
+
+// Compact row storage of the news-level training path (bf16, gather source, x_rows + row_ws given): x_rows and dqkv hold ONLY
+// the live rows (non-padding tokens), in live-list order -- the padding rows of both are never needed: a padding token
+// gathers the zero row (the projection substitutes the bias, the weight gradient would contract a zero row, padding_idx
+// gets no table gradient), and the one thing its dQ|dK|dV row feeds, the bias gradient, comes out of the attention backward
+// itself.  Halves the gradient stores of the attention backward and lets the weight-gradient GEMM contract 0.33 instead of
+// 0.57 of the rows of a MIND-shaped batch.  The forward and the backward call evaluate this same predicate.
+static bool mhsa_compact_rows(const nr_mhsa_desc* d) {
+  const int N = d->heads * d->d_head, M = d->n * d->L, Kp = round_up(d->d_model, nr_chunk(d->dtype));
+  return !nr_opt(NR_OPT_NO_COMPACT_ROWS) && !nr_opt(NR_OPT_NO_SLABS) && !nr_opt(NR_OPT_NO_ATTN_SKIP) && !nr_opt(NR_OPT_NO_SCATTER_SORT) &&
+         g_det_elems.load() == 0 && d->dtype == NR_BF16 && d->src_kind == NR_SRC_GATHER && d->x_rows != nullptr && d->row_ws != nullptr &&
+         d->b_qkv != nullptr && d->table_rows > 0 && M >= 4096 && M % 32 == 0 && (3 * N) % 8 == 0 && 3 * N <= 2048 && d->d_model % 4 == 0 &&
+         d->ld_rows >= Kp && nr_attn_compact_ok(d->dtype, d->L, d->d_head, d->heads) && nr_gemm_tn_slabs_ok(3 * N, d->ld_rows, M, 3 * N, Kp);
 }
 
 static int mhsa_check(const nr_mhsa_desc* d) {
@@ -577,10 +600,21 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
     // gather + dropout once into x_rows (kept for the backward), then a plain dense projection GEMM
     NR_CHECK_ARG(d->ld_rows >= Kp && d->ld_rows % nr_chunk(d->dtype) == 0, "mhsa_fwd: ld_rows=%d must cover %d", d->ld_rows, Kp);
     const bool compacting = d->row_ws != nullptr && d->dtype == NR_BF16 && M >= 4096 && (3 * N) % 8 == 0;
+    const bool cstore = compacting && mhsa_compact_rows(d);     // x_rows holds the live rows only, in live-list order
     // Padding tokens (id 0) gather the zero row of the table: their projection is the bias.  Project the live rows
     // only (compacted on the device) and write the bias into the others.  If table row 0 is not zero, the
     // compaction keeps every row and nothing changes.
-    if (compacting && (rc = nr_launch_compact_rows_fwd(d->ids, M, d->n, d->L, d->x, d->d_model, d->row_ws, s))) return rc;
+    if (compacting && (rc = nr_launch_compact_rows_fwd(d->ids, M, d->n, d->L, d->x, d->d_model, d->row_ws, s, cstore ? d->row_ws + W.pos : nullptr)))
+      return rc;
+    if (cstore) {
+      NR_CHECK_ARG(nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, y), "mhsa_fwd: qkv / y must be 8-byte aligned");
+      if ((rc = nr_launch_gather_live_rows(d->dtype, A, d->x_rows, d->ld_rows, M, Kp, d->row_ws, d->row_ws + W.live_idx, d->row_ws + W.live_ids, s)))
+        return rc;
+      A = dense_rows(d->x_rows, d->ld_rows, d->d_model);
+      ep.row_count = d->row_ws; ep.row_idx = d->row_ws + W.live_idx; ep.row_ids = d->row_ws + W.live_ids;
+      ep.a_dense = 1;                                  // A row k = live row k; row_idx scatters the output rows
+      tmask = reinterpret_cast<const uint32_t*>(d->row_ws + W.tmask);      // per-row substitution: no bias rows are written
+    } else {
     // under "needed" flags the rows of all-padding sequences no weight-gradient slab can reach are not even written
     // (only where the backward contracts live slabs: a dense contraction would read every row)
     const bool skip_far = compacting && d->seq_needed != nullptr && M % 32 == 0 && nr_gemm_tn_slabs_ok(3 * N, d->ld_rows, M, 3 * N, Kp) &&
@@ -600,6 +634,7 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
       if (!(tmask != nullptr && nr_attn_rowsub_ok(d->dtype, d->L, d->d_head, d->heads)) &&
           (rc = nr_launch_bias_rows(qkv, 3 * N, 3 * N, d->b_qkv, d->row_ws + W.dead_idx, d->row_ws + 1, M, tmask, d->L, s)))
         return rc;
+    }
     }
   }
   if ((rc = nr_launch_gemm_nt(d->dtype, A, d->w_qkv, d->ldw, M, 3 * N, Kp, EPI_STORE, ep, s))) return rc;
@@ -640,6 +675,43 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
     NR_CHECK_ARG(nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, dqkv) && (((uintptr_t)dy) & 7) == 0,
                  "mhsa_bwd: the forward left padding rows of qkv unwritten; qkv / dy / dqkv must be 8-byte aligned");
     tmask = reinterpret_cast<const uint32_t*>(d->row_ws + W.tmask);
+  }
+  if (d->row_ws_ready && mhsa_compact_rows(d)) {
+    // ---- compact row storage (see mhsa_compact_rows): x_rows holds the live rows in live-list order (forward), dqkv gets them
+    // in the same order; dW = dqkv_c^T . x_c over `count` dense rows, db from the attention kernel, the table gradient reads
+    // dqkv_c through the id-sorted positions
+    NR_CHECK_ARG(tmask != nullptr, "mhsa_bwd: the forward stored x_rows compactly; qkv / dy / dqkv must be 8-byte aligned");
+    NR_CHECK_ARG(dtable != nullptr && dx == nullptr && w_qkv_t != nullptr && ldwt >= 3 * N, "mhsa_bwd: gather source takes dtable (and w_qkv_t [d_model, >=3N])");
+    int32_t* ws = d->row_ws;
+    if (ph_main) {
+      int32_t* slab_ws = ws + W.slab;                  // n sequence flags: which sequences got a non-zero upstream gradient
+      if (d->seq_nz != nullptr) {
+        NR_CHECK_HIP(hipMemcpyAsync(slab_ws, d->seq_nz, (size_t)d->n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+      } else if ((rc = nr_launch_title_flags(dy, d->n, d->L, N, slab_ws, s))) {
+        return rc;
+      }
+      // the walk leaves out the all-padding sequences with a zero gradient (nothing to store, nothing to add to db); slab
+      // distances do not matter any more -- no slab is contracted -- so the list kernel runs with a zero reach
+      int32_t* seq_ws = ws + W.seq;
+      if ((rc = nr_launch_seq_list(slab_ws, tmask, d->n, d->L, seq_ws, s, /*reach=*/0))) return rc;
+      // rows count .. roundup32(count) of dqkv: the weight-gradient GEMM contracts whole 32-row slabs (x_c is zero there)
+      if ((rc = nr_launch_zero_tail_rows(dqkv, 3 * N, ws, M, s))) return rc;
+      if ((rc = nr_launch_attn_bwd_compact(qkv, d->mask, dy, dqkv, d->n, d->L, d->heads, d->d_head, nr_make_drop(d->p_out, d->seed_out), s, tmask,
+                                           d->b_qkv, seq_ws + 4, seq_ws, ws + W.pos, ws + W.dump, db_qkv)))
+        return rc;
+      // table gradient: rows in token-id order, A rows through their live-list positions
+      if ((rc = nr_launch_sort_rows_by_id(ws, ws + W.live_idx, ws + W.live_ids, M, d->table_rows, ws + W.hist, ws + W.sort_idx, ws + W.sort_ids, s,
+                                          ws + W.sort_k)))
+        return rc;
+      EpiArgs ep = store_epi(dtable, d->d_model, NR_F32, nullptr, 0);
+      ep.ids = d->ids; ep.ids_stride = 1; ep.Dtrue = d->d_model; ep.drop = nr_make_drop(d->p_in, d->seed_in);
+      ep.row_count = ws; ep.row_idx = ws + W.sort_idx; ep.row_ids = ws + W.sort_ids; ep.a_idx = ws + W.sort_k;
+      RowSrc G = dense_rows(dqkv, 3 * N, 3 * N);
+      if ((rc = nr_launch_gemm_nt(d->dtype, G, w_qkv_t, ldwt, M, d->d_model, 3 * N, EPI_SCATTER, ep, s))) return rc;
+    }
+    if (ph_dw && (rc = nr_launch_gemm_tn_counted(dqkv, 3 * N, d->x_rows, d->ld_rows, dw_qkv, d->d_model, M, 3 * N, Kp, 3 * N, d->d_model, ws, s)))
+      return rc;
+    return NR_OK;
   }
   // Sequences whose upstream gradient dy is exactly zero (history slots the user encoder masks out) get exact zeros in
   // dQ|dK|dV (dP = dy.V^T = 0, so dS = 0): a pass over dy flags the others, and the weight-gradient GEMM contracts only
@@ -772,7 +844,11 @@ int nr_conv1d_k3_fwd(const nr_conv_desc* d, void* y, nr_stream_t stream) {
   NR_CHECK_ARG(y != nullptr, "conv1d_fwd: null output");
   NR_DEVICE_GUARD(stream, y);
   EpiArgs ep = store_epi(y, d->N, d->dtype, d->bias, 0);
-  ep.seq_nz = d->seq_needed; ep.L = d->T;          // row tiles made of unneeded titles only are not computed
+  // Row tiles made of unneeded titles only are not computed and their y rows stay UNWRITTEN -- but only on shapes whose
+  // consumers contract live slabs (the pooling backward's dW1 = dpre^T . y): a dense contraction (small shapes) multiplies every
+  // row by its zero gradient, and 0 x whatever the allocator left there is NaN (seen once the title table stopped being the
+  // first big allocation: tests/test_gpu_model_parity.py, naml_mind_3view)
+  ep.seq_nz = conv_slab_shape(d) ? d->seq_needed : nullptr; ep.L = d->T;
   hipStream_t s = (hipStream_t)stream;
   const int M = d->n * d->T, K = 3 * d->Dp;
   if (d->x_rows != nullptr) {

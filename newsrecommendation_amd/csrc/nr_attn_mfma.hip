@@ -44,6 +44,12 @@ struct AttnMArgs {
   const int32_t* needed;  // optional (forward, bf16 panel kernel) [n]: 0 = nobody uses this sequence's output: zeros are stored
   const int32_t* ids;     // optional (forward, bf16 panel kernel) [n*L]: row m of Q|K|V is qkv[ids[m]] -- `qkv` is then a
                           //   per-token-id table of projections (eval mode: W x + b depends on the token id only)
+  // Compact row storage (backward, bf16 panel kernel with per-row padding substitution, L <= 31):
+  const int32_t* pos;     // [n*L]: dQ|dK|dV of token row m is stored at dqkv row pos[m]; pos[m] < 0 (a padding token: nothing
+                          //   downstream reads its gradient row) is not stored at all
+  void* dump;             // 3N elements of scratch: where the (unpredicated) stores of an all-padding sequence land
+  float* db;              // [3N] fp32, ACCUMULATED: column sums of dQ | dK | dV over every row of every sequence walked -- the bias
+                          //   gradient, produced here because the padding rows that carry part of it are no longer stored
 };
 
 __device__ __forceinline__ int rowof(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -931,7 +937,8 @@ __global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
   }
 }
 
-template <bool HAS_MASK, int PT, bool SUB, bool FULL = false, int LC = 0, int DC = 0, int HC = 0, int OCC = 3>
+template <bool HAS_MASK, int PT, bool SUB, bool FULL = false, int LC = 0, int DC = 0, int HC = 0, int OCC = 3, bool CPT = false>
+// CPT (needs FULL && SUB, L <= 31): compact row storage + bias gradient, see AttnMArgs::pos / dump / db
 // OCC = waves per SIMD the register allocation aims at.  The generic instantiations need ~160 VGPRs and spill heavily under a
 // 128 cap (1.6 - 2.3 ms instead of 0.75); the shape-specialised one fitted 128 before the per-row padding substitution and
 // spills a little with it -- 3 waves without spills win (NR_ATTN_BWD_OCC4 keeps the other build selectable)
@@ -949,6 +956,7 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
   bf16_t *sQ = imQ + wo, *sK = imK + wo, *sV = imV + wo, *sG = imG + wo;
   float* sF = reinterpret_cast<float*>(img0 + (size_t)4 * MS) + wid * 128;
   float *sMask = sF, *sM = sF + 32, *sInv = sF + 64, *sRd = sF + 96;
+  static_assert(!CPT || (FULL && SUB), "compact row storage rides on the per-row padding substitution");
   const int L = LC ? LC : a.L, d = DC ? DC : a.d, heads = HC ? HC : a.heads;
   const int N = heads * d, N3 = 3 * N;
   const bf16_t* qkv = reinterpret_cast<const bf16_t*>(a.qkv);
@@ -963,6 +971,16 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     for (int i = tid; i < N3; i += AW * 64) sBias[i] = (bf16_t)a.bias[i];
 
   const int hgroups = (heads + AW - 1) / AW, stride = gridDim.x;
+  // CPT: behind the bias table -- [32] positions of the current item's rows | per wave 3 x [32] sums | the bias-gradient
+  // accumulators [hgroups][AW][3][32] (column c of head slot w of group hg of matrix Q / K / V)
+  int* sPos = reinterpret_cast<int*>(sBias + ((N3 + 7) / 8) * 8);
+  float* sCs = reinterpret_cast<float*>(sPos + 32) + wid * 96;      // per wave: column sums of dS | row sums of dS | row sums of P
+  float *sRs = sCs + 32, *sRho = sCs + 64;
+  float* sDb = reinterpret_cast<float*>(sPos + 32) + AW * 96;
+  if (CPT)
+    for (int i = tid; i < hgroups * AW * 96; i += AW * 64) sDb[i] = 0.f;
+  int pos_next = 0;                                      // CPT: dqkv row of token (tid & 31) of the prefetched sequence
+  uint32_t tm_cur = 0;                                   // CPT: live-token mask of the CURRENT item's sequence
   ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};
   Panel<PT> rq, rk, rv, rg;
   bool dead_next = false;
@@ -999,6 +1017,7 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
       panel_load_sub(rk, qkv, so, N + hd, N3, pc, tm_seq);
       panel_load_sub(rv, qkv, so, 2 * N + hd, N3, pc, tm_seq);
       panel_load_all(rg, dy + r0 * N + hd, N, pc);
+      if (CPT) pos_next = a.pos[(uint32_t)r0 + (uint32_t)min(tid & 31, L - 1)];     // every thread, every item: same instruction count
     } else if (FULL) {
       const bf16_t* src = qkv + (dead_next ? (size_t)0 : r0 * N3) + hd;   // dead: any valid rows (L2 hits), ignored
       panel_load_all(rq, src, N3, pc);
@@ -1037,6 +1056,10 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     }
     panel_put<true, PT, FULL>(rg, imG, pc, a.drop, (uint32_t)(r0 * N) + (uint32_t)(t.hg * AW * d), N);
     if (HAS_MASK && lane < 32) sMask[lane] = (lane < L && t.hg * AW + wid < heads) ? a.mask[r0 + lane] : 0.f;
+    if (CPT) {
+      if (tid < 32) sPos[tid] = pos_next;
+      tm_cur = tm_seq;                                   // (put follows the item's own prefetch: tm_seq is still its mask)
+    }
   };
   __syncthreads();                                       // images zeroed, bias table in LDS
   if (nseq <= (int)blockIdx.x) return;                   // uniform: nothing for this workgroup
@@ -1086,6 +1109,12 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         sM[lane] = mc;
         sInv[lane] = inv;
         sRd[lane] = rd;
+        if (CPT) {
+          // row sums of query li (0 for the padded queries): sum_j P_ij = rho = 1 - er, sum_j dS_ij = scale * rd * (1 - rho)
+          const float er = 1e-8f * __builtin_amdgcn_exp2f(-mc) * inv;
+          sRs[lane] = li < L ? a.scale * rd * er : 0.f;
+          sRho[lane] = li < L ? 1.f - er : 0.f;
+        }
       }
     }
     __syncthreads();
@@ -1093,7 +1122,7 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-      mm_xt_T(dq, dst, sK, lane); // dQ^T[c][i] = sum_j K[j][c] dS[i][j] / sqrt(d)
+      if (!CPT) mm_xt_T(dq, dst, sK, lane); // dQ^T[c][i] = sum_j K[j][c] dS[i][j] / sqrt(d)
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -1108,10 +1137,63 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
         s[r] = pij;
         dp[r] = pij * a.scale * (dp[r] - sRd[i]);
       }
+      if (CPT) {
+        // Bias gradient without storing the padding rows: db_q = sum_j (sum_i dS_ij) K_j, db_k = sum_i (sum_j dS_ij) Q_i,
+        // db_v = sum_i (sum_j P_ij) G_i.  The three row / column sums travel through the products below as ONE EXTRA token
+        // -- column 31 of the 32 x 32 tiles, free because L <= 31 -- and come out in lanes 31 / 63 of dq / dk / dv:
+        //   dS   column 31 (lane 31, registers = queries i) <- row sums of dS = scale * rd_i * (1 - rho_i)      (sRs, phase 1)
+        //   P    column 31                                  <- rho_i = sum_j P_ij = 1 - 1e-8 * exp2(-m_i c) * inv_i   (sRho)
+        //   dS^T column 31 (lane 31, registers = keys j)    <- column sums of dS   (this lane's registers, via LDS)
+        // dQ is computed LAST here (dS^T stays live instead of dQ across the other two products: same register peak)
+        float cs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs += dp[r];
+        cs += __shfl_xor(cs, 32, 64);
+        if (lane < 32) sCs[lane] = cs;
+        const bool x31 = li == 31;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                      // registers 4k .. 4k+3 = queries 8k + 4 h2 .. + 3
+          const f32x4 rs4 = *reinterpret_cast<const f32x4*>(sRs + 8 * k + 4 * h2), rh4 = *reinterpret_cast<const f32x4*>(sRho + 8 * k + 4 * h2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            dp[4 * k + e] = x31 ? rs4[e] : dp[4 * k + e];
+            s[4 * k + e] = x31 ? rh4[e] : s[4 * k + e];
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
       mm_xt_T(dk, dp, sQ, lane);  // dK^T[c][j] = sum_i Q[i][c] dS[i][j] / sqrt(d)
       mm_xt_T(dv, s, sG, lane);   // dV^T[c][j] = sum_i G[i][c] P[i][j]
+    }
+    if (CPT) {
+      {
+        const bool x31 = li == 31;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                      // registers 4k .. 4k+3 = keys 8k + 4 h2 .. + 3 (the wave's own LDS words)
+          const f32x4 c4 = *reinterpret_cast<const f32x4*>(sCs + 8 * k + 4 * h2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[4 * k + e] = x31 ? c4[e] : dst[4 * k + e];
+        }
+        mm_xt_T(dq, dst, sK, lane);
+      }
+      if (CPT && li == 31) {
+        // lanes 31 / 63: the item's bias-gradient contribution, columns c = 8k + 4 h2 + e of this wave's head; only these two
+        // lanes ever touch the wave's accumulator rows, so a plain read-modify-write is enough
+        float* acc = sDb + ((it.hg * AW + wid) * 3) * 32 + 4 * h2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          if (8 * k + 4 * h2 < d) {
+            f32x4 q4 = *reinterpret_cast<f32x4*>(acc + 8 * k), k4 = *reinterpret_cast<f32x4*>(acc + 32 + 8 * k),
+                  v4 = *reinterpret_cast<f32x4*>(acc + 64 + 8 * k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { q4[e] += dq[4 * k + e]; k4[e] += dk[4 * k + e]; v4[e] += dv[4 * k + e]; }
+            *reinterpret_cast<f32x4*>(acc + 8 * k) = q4;
+            *reinterpret_cast<f32x4*>(acc + 32 + 8 * k) = k4;
+            *reinterpret_cast<f32x4*>(acc + 64 + 8 * k) = v4;
+          }
+        }
+      }
     }
     // stored straight from the registers: routing dQ/dK/dV through LDS panels like the forward output measured
     // slower here (1.38 vs 1.18 ms)
@@ -1128,7 +1210,24 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
       __syncthreads();
       bf16_t* op = dqkv + row0 * N3 + it.hg * AW * d;
       const int hcount = min(AW, heads - it.hg * AW);
-      if (FULL) {
+      if (CPT) {
+        // compact storage: token row r goes to dqkv row sPos[r]; a padding row (bit r of tm_cur clear) is not stored -- its
+        // slot re-stores the sequence's first live row instead (same bytes twice: the instruction count stays uniform); a
+        // sequence without any live row stores into the dump row
+        const bool dead = tm_cur == 0;                     // wave-uniform
+        const uint32_t r0l = dead ? 0u : (uint32_t)__builtin_ctz(tm_cur);
+        bf16_t* base = dead ? reinterpret_cast<bf16_t*>(a.dump) : dqkv;
+        const uint32_t hcol = (uint32_t)(it.hg * AW * d);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+          const uint32_t row = (uint32_t)pc.row(t), re = ((tm_cur >> row) & 1u) ? row : r0l;
+          const uint32_t off = (dead ? 0u : (uint32_t)sPos[re] * (uint32_t)N3) + hcol + (uint32_t)pc.q4(t);
+          const bf16_t* src = img0 + re * ops + pc.q4(t);
+          *reinterpret_cast<bf16x4*>(base + off) = *reinterpret_cast<const bf16x4*>(src);
+          *reinterpret_cast<bf16x4*>(base + off + N) = *reinterpret_cast<const bf16x4*>(src + 32 * ops);
+          *reinterpret_cast<bf16x4*>(base + off + 2 * N) = *reinterpret_cast<const bf16x4*>(src + 64 * ops);
+        }
+      } else if (FULL) {
         panel_store_all<PT>(img0, ops, op, N3, pc);
         panel_store_all<PT>(img0 + 32 * ops, ops, op + N, N3, pc);
         panel_store_all<PT>(img0 + 64 * ops, ops, op + 2 * N, N3, pc);
@@ -1146,6 +1245,14 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     __syncthreads();   // every wave has read the output panels (they alias the Q / V images)
     put(pf);           // next item -> images
     __syncthreads();
+  }
+  if (CPT) {
+    // this workgroup's share of the bias gradient: 3N fp32 atomics (4096 workgroups x 4.8 KB: ~15 us of the chip's atomic rate)
+    // (plain fp32 atomics: the caller does not use compact storage in deterministic mode)
+    for (int i = tid; i < hgroups * AW * 96; i += AW * 64) {
+      const int c = i & 31, mat = (i >> 5) % 3, head = i / 96;                   // accumulator slot hg * AW + w = head
+      if (c < d && head < heads) atomicAdd(a.db + mat * N + head * d + c, sDb[i]);
+    }
   }
 }
 
@@ -1635,7 +1742,10 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   const size_t smem = bwd ? AW * (4 * (IMG + HPAD) * sizeof(bf16_t) + 128 * sizeof(float))
                           : AW * ((3 * IMG + HPAD) * sizeof(bf16_t) + 32 * sizeof(float)) + panel;
   const bool p3 = a.L * a.d <= 768, sub = a.tmask != nullptr;
-  const size_t smem_s = smem + (sub ? (size_t)3 * a.N * sizeof(bf16_t) : 0);
+  const bool cpt = bwd && a.pos != nullptr;              // compact row storage + bias gradient (see bwd_kernel, CPT)
+  const int hgroups = (a.heads + AW - 1) / AW;
+  const size_t smem_s = smem + (sub ? (size_t)((3 * a.N + 7) / 8) * 8 * sizeof(bf16_t) : 0) +
+                        (cpt ? (size_t)(32 + AW * 96 + hgroups * AW * 96) * sizeof(float) : 0);
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(AW * 64), smem_s, stream, a); };
   // FULL: all head slots real and the store panels alias the images (d <= 21 in the backward): unpredicated memory
   // instructions, counted waits (see fwd_kernel)
@@ -1644,7 +1754,13 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   const bool title30 = full && p3 && a.L == 30 && a.d == 20 && a.heads == 20 && !nr_opt(NR_OPT_ATTN_GENERIC);   // the reference's defaults
   auto pick = [&](auto tag_mask, auto tag_sub) {
     constexpr bool HM = decltype(tag_mask)::value, SB = decltype(tag_sub)::value;
-    if (bwd) {
+    if (bwd && cpt) {
+      // (launcher contract: FULL shape with per-row substitution, L <= 31)
+      if constexpr (SB) {
+        if (title30) go(bwd_kernel<HM, 3, true, true, 30, 20, 20, 3, true>);
+        else p3 ? go(bwd_kernel<HM, 3, true, true, 0, 0, 0, 3, true>) : go(bwd_kernel<HM, 4, true, true, 0, 0, 0, 3, true>);
+      }
+    } else if (bwd) {
       // 3 waves per SIMD without spills beat 4 with the 11 scratch accesses per item the row substitution pushes the
       // 128-VGPR build into (same box: 0.74 vs 0.91 ms)
       if (title30) nr_opt(NR_OPT_ATTN_BWD_OCC4) ? go(bwd_kernel<HM, 3, SB, true, 30, 20, 20, 4>) : go(bwd_kernel<HM, 3, SB, true, 30, 20, 20, 3>);
@@ -1709,6 +1825,7 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   if (!nr_attn_mfma_supported(L, d_head)) return -1;
   AttnMArgs a;
   a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr; a.ids = nullptr; a.needed = needed;
+  a.pos = nullptr; a.dump = nullptr; a.db = nullptr;
   a.qkv = qkv; a.mask = mask; a.y = y; a.dy = dy; a.dqkv = dqkv;
   a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;
   a.scale = 1.0f / sqrtf((float)d_head);
@@ -1735,6 +1852,29 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
 }
 
 
+bool nr_attn_rowsub_ok(int dtype, int L, int d_head, int heads);
+// Backward with compact row storage (see AttnMArgs::pos / dump / db): the caller checked nr_attn_compact_ok.
+bool nr_attn_compact_ok(int dtype, int L, int d_head, int heads) { return nr_attn_rowsub_ok(dtype, L, d_head, heads) && L <= 31; }
+
+int nr_launch_attn_bwd_compact(const void* qkv, const float* mask, const void* dy, void* dqkv, int n, int L, int heads, int d_head,
+                               const DropCfg& drop, hipStream_t stream, const uint32_t* tmask, const float* bias, const int32_t* seq_list,
+                               const int32_t* seq_count, const int32_t* pos, void* dump, float* db) {
+  NR_CHECK_ARG(nr_attn_compact_ok(NR_BF16, L, d_head, heads) && tmask && bias && pos && dump && db && qkv && dy && dqkv,
+               "attention backward (compact rows): shape or operands not eligible");
+  NR_CHECK_ARG(((((uintptr_t)qkv) | ((uintptr_t)dy) | ((uintptr_t)dqkv) | ((uintptr_t)dump)) & 7) == 0, "attention backward (compact rows): 8-byte alignment");
+  AttnMArgs a;
+  a.ids = nullptr; a.needed = nullptr; a.y = nullptr;
+  a.qkv = qkv; a.mask = mask; a.dy = dy; a.dqkv = dqkv;
+  a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;
+  a.scale = 1.0f / sqrtf((float)d_head);
+  a.drop = drop;
+  a.vec = 1;
+  a.tmask = tmask; a.bias = bias; a.seq_list = seq_list; a.seq_count = seq_list ? seq_count : nullptr;
+  a.pos = pos; a.dump = dump; a.db = db;
+  NrProfScope ps(stream, "attn_mfma_bwd_rows[bf16,n=%d,L=%d,h=%d,d=%d]", n, L, heads, d_head);
+  return b16::launch(true, a, stream);
+}
+
 // True when the bf16 panel kernels substitute the bias for padding ROWS themselves (FULL + live-token masks): the projection
 // then need not write the bias into the padding rows of partly live sequences (nr_launch_bias_rows), nobody reads them.
 bool nr_attn_rowsub_ok(int dtype, int L, int d_head, int heads) {
@@ -1750,6 +1890,7 @@ int nr_launch_attn_gather_fwd(const void* proj_table, const int32_t* ids, const 
   if ((!nr_attn_pad_ok(NR_BF16, L, d_head, proj_table, y) && !long_seq) || ids == nullptr) return -1;
   AttnMArgs a;
   a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr; a.needed = nullptr;
+  a.pos = nullptr; a.dump = nullptr; a.db = nullptr;
   a.ids = ids;
   a.qkv = proj_table; a.mask = mask; a.y = y; a.dy = nullptr; a.dqkv = nullptr;
   a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;

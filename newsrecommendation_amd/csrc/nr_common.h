@@ -96,6 +96,7 @@ enum NrOpt {
   NR_OPT_NT_WREG,        // 1 (default): skinny-K bf16 NT GEMMs with the weights held in registers (persistent, LDS ring of activation rows); 3: the same with 16-row instead of 32-row stages for the QKV shape; 0: tile kernels
   NR_OPT_NO_SCATTER_SORT, // 1: the table-gradient GEMM walks the live rows in batch order instead of token-id order
   NR_OPT_TN3_MIN_M,      // smallest row count that takes the LDS-DMA weight-gradient kernel (default 16384)
+  NR_OPT_NO_COMPACT_ROWS, // 1: x_rows / dqkv of the news-level training path keep one row per token (no compact row storage)
   NR_OPT_COUNT
 };
 int nr_opt(int which);

@@ -52,6 +52,8 @@ struct EpiArgs {
   void* rows_out;         // optional: the staged A rows (after gather / dropout), dtype, [M, ld_rows_out]
   int ld_rows_out;
   int a_gap;              // LDS-DMA kernel: RowSrc::gap of the A operand (set by the launcher)
+  const int32_t* a_idx;   // with row_count: the A row of compacted row m is a_idx[m] (A itself stored in live-list order) instead of row_idx[m]
+  int a_dense;            // with row_count (weights-in-registers kernel): A row of compacted row m is m itself; row_idx only scatters the output
 };
 
 // C-level launchers (enqueue only).  dtype selects T.
@@ -71,12 +73,14 @@ int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, i
 int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* ws, hipStream_t stream);
 // live rows (count on the device, their row numbers and token ids) -> the same rows grouped by token id (counting sort:
 // hist int32 [table_rows + 8] scratch).  Order inside a group is arbitrary.
+// k_out (optional): position of each sorted row in the unsorted live list
 int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const int32_t* ids, int Mmax, int table_rows, int32_t* hist,
-                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream);
+                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream, int32_t* k_out = nullptr);
 // forward flavour: ws int32 [3*M + n + 4] (adds ws[1] = dead count, ws[2] = "table row 0 is not zero", ws[4+2M ..] dead rows,
 // ws[4+3M ..] per-sequence live-token bit masks when L <= 32)
+// posmap (optional [M]): position of every row in the live list (-1: dead)
 int nr_launch_compact_rows_fwd(const int32_t* ids, int M, int n, int L, const void* table_row0, int cols, int32_t* ws,
-                               hipStream_t stream);
+                               hipStream_t stream, int32_t* posmap = nullptr);
 // tmask (optional, with L): rows of sequences whose live-token mask is 0 are skipped (the attention kernels cover them)
 int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_t* rows, const int32_t* count, int max_rows,
                         const uint32_t* tmask, int L, hipStream_t stream);
@@ -85,9 +89,16 @@ int nr_launch_title_flags(const void* dy, int n, int L, int N, int32_t* title_nz
 int nr_launch_row_flags_f32(const float* g, int ld, int N, int n, int32_t* nz, hipStream_t stream);
 int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream);
 int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream);
-int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream);
+// reach: an all-padding sequence is left out when its own and `reach` neighbours' gradients are zero (-1: 32 / L + 2, the span of a slab)
+int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream, int reach = -1);
+int nr_launch_zero_tail_rows(void* buf, int ld, const int32_t* count, int Mmax, hipStream_t stream);
 int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K,
                             int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream, int xgap = 0);
 bool nr_gemm_tn_slabs_ok(int ldc, int ldx, int M, int N, int K);
+int nr_launch_gemm_tn_counted(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, int Mmax, int N, int K, int Nstore,
+                              int Kstore, const int32_t* row_count, hipStream_t stream);
+// live rows only, in live-list order (count / rows / ids of nr_launch_compact_rows_fwd), zero-filled to a multiple of 32 rows
+int nr_launch_gather_live_rows(int dtype, const RowSrc& A, void* out, int ldo, int Mmax, int K, const int32_t* count, const int32_t* rows,
+                               const int32_t* ids, hipStream_t stream);
 int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db,
                       int M, int N, int K, int Nstore, int Kstore, hipStream_t stream);

@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
     const int p = pfirst + t;
     if (p < DBM / 16) {
       int arow = min(m0 + 16 * p + prow, M - 1);
-      if (compact) arow = ep.row_idx[arow];        // compacted row -> row of A
+      if (compact) arow = (ep.a_idx != nullptr ? ep.a_idx : ep.row_idx)[arow];   // compacted row -> row of A (a_idx: A is stored compactly)
       if (ep.a_gap > 0) arow += arow / ep.a_gap;   // token rows with a zero row between titles (RowSrc::gap)
       src[t] = A + (size_t)arow * lda + c8;
       isA[t] = true;
@@ -1611,7 +1611,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restr
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       const int row = blk(kk) * R + 16 * i + prow;
-      arow[i] = (kk >= nsteps || row >= M) ? 0 : (COMPACT ? ep.row_idx[row] : row);
+      arow[i] = (kk >= nsteps || row >= M) ? 0 : ((COMPACT && !ep.a_dense) ? ep.row_idx[row] : row);
     }
   };
 #pragma unroll 1
@@ -1644,7 +1644,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restr
       for (int i = 0; i < RT; ++i) {
         const int rown = bn * R + 16 * i + prow;
         const bool ok = k + NS - 1 < nsteps && rown < M;
-        ar[i] = !ok ? 0 : (COMPACT ? rid[R + 16 * i + prow] : rown);
+        ar[i] = !ok ? 0 : ((COMPACT && !ep.a_dense) ? rid[R + 16 * i + prow] : rown);
         mout[i] = COMPACT ? rid[16 * i + fr] : b * R + 16 * i + fr;
       }
     }
@@ -1870,15 +1870,20 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
   const int n0 = tn * TBN, k0 = tk * TBK;
   // Slab mode: only the 32-row slabs listed on the device are contracted (the others are known to be all zero in dC);
   // the list is divided evenly over the splits and this split's part is staged in LDS.
+  // Counted mode (slab_list == nullptr, slab_count != nullptr): the operands are dense but only their first *slab_count
+  // ROWS exist (compactly stored live rows, zero-filled up to the next multiple of 32): slabs 0 .. ceil(count / 32).
   __shared__ int sSlab[1024];
-  const bool slabs = slab_list != nullptr;
-  int mbeg = split * rps, nk;
-  if (slabs) {
-    const int total = *slab_count, per = (total + nsplit - 1) / nsplit, kbeg = split * per;
+  const bool slabs = slab_list != nullptr, counted = !slabs && slab_count != nullptr;
+  int mbeg = split * rps, nk, kbeg = 0;
+  if (slabs || counted) {
+    const int total = counted ? (*slab_count + TBM - 1) / TBM : *slab_count, per = (total + nsplit - 1) / nsplit;
+    kbeg = split * per;
     nk = min(per, total - kbeg);
     if (nk <= 0) return;
-    for (int i = threadIdx.x; i < nk; i += blockDim.x) sSlab[i] = slab_list[kbeg + i];
-    __syncthreads();
+    if (slabs) {
+      for (int i = threadIdx.x; i < nk; i += blockDim.x) sSlab[i] = slab_list[kbeg + i];
+      __syncthreads();
+    }
     mbeg = 0;
   } else {
     const int mend = min(M, mbeg + rps);
@@ -1913,7 +1918,7 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
   }
   const uint32_t ginv = xgap > 0 ? (uint32_t)((0x100000000ull + (uint32_t)xgap - 1) / (uint32_t)xgap) : 0u;   // ceil(2^32 / xgap)
   auto issue = [&](int stage, int kt) {
-    const size_t sl = slabs ? (size_t)sSlab[kt] : (size_t)kt;
+    const size_t sl = slabs ? (size_t)sSlab[kt] : (size_t)(kbeg + kt);      // (kbeg = 0 unless counted)
 #pragma unroll
     for (int t = 0; t < PB + 1; ++t)
       if (t < PB || extra) {
@@ -2037,9 +2042,10 @@ int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw
   const int grid = ((nsplit + 7) / 8) * 8 * ntile;
   auto kern = gemm_tn3_kernel<WK, NI>;
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM));
+  const bool counted = slab_list == nullptr && slab_count != nullptr;           // dense rows, device-side row count
   if (slab_list != nullptr && (M / TBM + nsplit - 1) / nsplit > 1024) slab_list = nullptr;   // a split's list must fit its LDS stage
   hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::SMEM, stream, (const bf16_t*)dC, ldc, (const bf16_t*)X, ldx, dW, ldw, db, M, N,
-                     K, Nstore, Kstore, tilesK, ntile, nsplit, rps, slab_list, slab_list ? slab_count : nullptr, xgap);
+                     K, Nstore, Kstore, tilesK, ntile, nsplit, rps, slab_list, (slab_list || counted) ? slab_count : nullptr, xgap);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -2240,6 +2246,49 @@ __global__ __launch_bounds__(256) void gather_title_kernel(RowSrc A, T* __restri
   }
 }
 
+// Compact row storage (news level, training): ONLY the live rows of the gathered + dropped-out operand are materialised,
+// in live-list order: out[k] = dropout(table[ids[k]]) with the dropout counter of the ORIGINAL row rows[k] (the draws are
+// those of the dense computation).  A padding token gathers the zero row and no kernel downstream needs it: the
+// projection substitutes the bias, the weight gradient would multiply a zero row.  Rows count .. roundup32(count) are
+// zero-filled (the weight-gradient GEMM contracts whole 32-row slabs).  Four independent (index -> table -> store) chains
+// per thread: the gather is latency bound, not bandwidth bound, with one (rows_materialize ran at 2.9 TB/s).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_live_rows_kernel(RowSrc A, T* __restrict__ out, int ldo, int K, const int32_t* __restrict__ count,
+                                                               const int32_t* __restrict__ rows, const int32_t* __restrict__ ids) {
+  constexpr int CH = 16 / (int)sizeof(T), U = 4;
+  const int cpr = K / CH, n = *count, nz = (n + 31) / 32 * 32;
+  const uint32_t total = (uint32_t)nz * (uint32_t)cpr, stride = gridDim.x * 256u;
+  const uint32_t inv_cpr = (uint32_t)((0x100000000ull + (uint32_t)cpr - 1) / (uint32_t)cpr);
+  for (uint32_t u0 = blockIdx.x * 256u + threadIdx.x; u0 < total; u0 += U * stride) {
+    int k[U], c[U], row[U], id[U];
+    Chunk v[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t u = u0 + (uint32_t)j * stride;
+      uint32_t q = __umulhi(u, inv_cpr);                 // u / cpr (exact after one correction, u < 2^31)
+      if (q * (uint32_t)cpr > u) --q;
+      k[j] = (int)q;
+      c[j] = (int)(u - q * (uint32_t)cpr) * CH;
+      const bool ok = u < total && k[j] < n;
+      row[j] = ok ? rows[k[j]] : -1;
+      id[j] = ok ? ids[k[j]] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      v[j].u = make_uint4(0, 0, 0, 0);
+      if (row[j] >= 0) v[j].u = *reinterpret_cast<const uint4*>((const T*)A.base + (size_t)id[j] * A.ld + c[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const uint32_t u = u0 + (uint32_t)j * stride;
+      if (u >= total) continue;
+      if (row[j] >= 0 && A.drop.thresh && (v[j].u.x | v[j].u.y | v[j].u.z | v[j].u.w) != 0u)
+        drop_chunk<T>(v[j], A.drop, (uint32_t)row[j] * (uint32_t)A.Dtrue + (uint32_t)c[j], c[j], A.Dtrue);
+      *reinterpret_cast<uint4*>(out + (size_t)k[j] * ldo + c[j]) = v[j].u;
+    }
+  }
+}
+
 // Row compaction for the table-gradient GEMM: rows with token id 0 add nothing (padding_idx), and in a MIND-shaped
 // batch they are ~70 % of all rows (zero-padded title tails, empty history slots).  One pass, no host round trip:
 // 256 rows per workgroup, order kept inside a workgroup, workgroups append through one atomic counter.
@@ -2247,9 +2296,10 @@ namespace {
 // ws: [0] live count, [1] dead count, [4 .. 4+M) live rows, [4+M .. 4+2M) their ids, [4+2M .. 4+3M) dead rows (if DEAD).
 // all_live (device flag, may be null): when set every row counts as live (table row 0 is not zero, so a padding token
 // does not gather a zero row and the forward may not treat it as one).
+// posmap (optional, [M]): position of row m in the live list, -1 for a dead row (the inverse of ws[4 ..]).
 template <bool DEAD>
 __global__ __launch_bounds__(256) void compact_rows_kernel(const int32_t* __restrict__ ids, int stride, int M, int32_t* __restrict__ ws,
-                                                           const int32_t* __restrict__ all_live) {
+                                                           const int32_t* __restrict__ all_live, int32_t* __restrict__ posmap) {
   constexpr int RPT = 4;                                  // 1024 rows per workgroup: 4 batches of 256, order preserved
   __shared__ int wave_cnt[RPT][4];
   __shared__ int base, dbase;
@@ -2286,6 +2336,7 @@ __global__ __launch_bounds__(256) void compact_rows_kernel(const int32_t* __rest
     } else if (DEAD && m < M) {
       ws[4 + 2 * M + dbase + (j * 256 + tid - pos)] = m;
     }
+    if (posmap != nullptr && m < M) posmap[m] = live ? base + pos : -1;
     before += wave_cnt[j][0] + wave_cnt[j][1] + wave_cnt[j][2] + wave_cnt[j][3];
   }
 }
@@ -2352,7 +2403,8 @@ int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* w
   NR_CHECK_ARG(ids != nullptr && ws != nullptr && M > 0 && ids_stride >= 1, "compact_rows: bad arguments");
   NR_CHECK_HIP(hipMemsetAsync(ws, 0, 4 * sizeof(int32_t), stream));
   NrProfScope ps(stream, "compact_rows[M=%d]", M);
-  hipLaunchKernelGGL(compact_rows_kernel<false>, dim3((M + 1023) / 1024), dim3(256), 0, stream, ids, ids_stride, M, ws, (const int32_t*)nullptr);
+  hipLaunchKernelGGL(compact_rows_kernel<false>, dim3((M + 1023) / 1024), dim3(256), 0, stream, ids, ids_stride, M, ws, (const int32_t*)nullptr,
+                     (int32_t*)nullptr);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -2419,7 +2471,8 @@ __global__ __launch_bounds__(1024) void id_scan_kernel(int32_t* __restrict__ his
 }
 __global__ __launch_bounds__(256) void id_scatter_kernel(const int32_t* __restrict__ count, const int32_t* __restrict__ rows,
                                                          const int32_t* __restrict__ ids, int V, int32_t* __restrict__ cursor,
-                                                         int32_t* __restrict__ rows_out, int32_t* __restrict__ ids_out) {
+                                                         int32_t* __restrict__ rows_out, int32_t* __restrict__ ids_out,
+                                                         int32_t* __restrict__ k_out) {
   const int n = *count;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const int id = ids[i];
@@ -2427,13 +2480,14 @@ __global__ __launch_bounds__(256) void id_scatter_kernel(const int32_t* __restri
       const int pos = atomicAdd(cursor + id, 1);
       rows_out[pos] = rows[i];
       ids_out[pos] = id;
+      if (k_out != nullptr) k_out[pos] = i;          // position in the (unsorted) live list: the row of a compactly stored operand
     }
   }
 }
 }  // namespace
 
 int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const int32_t* ids, int Mmax, int table_rows, int32_t* hist,
-                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream) {
+                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream, int32_t* k_out) {
   NR_CHECK_ARG(count && rows && ids && hist && rows_out && ids_out && Mmax > 0 && table_rows > 0, "sort_rows_by_id: bad arguments");
   NrProfScope ps(stream, "sort_rows_by_id[Mmax=%d,V=%d]", Mmax, table_rows);
   NR_CHECK_HIP(hipMemsetAsync(hist, 0, (size_t)table_rows * sizeof(int32_t), stream));
@@ -2445,7 +2499,7 @@ int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const i
     NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(id_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 1024 * 4));
   }
   hipLaunchKernelGGL(id_scan_kernel, dim3(1), dim3(1024), in_lds ? (size_t)((table_rows + 3) / 4) * 16 : 0, stream, hist, table_rows, in_lds);
-  hipLaunchKernelGGL(id_scatter_kernel, dim3(grid), dim3(256), 0, stream, count, rows, ids, table_rows, hist, rows_out, ids_out);
+  hipLaunchKernelGGL(id_scatter_kernel, dim3(grid), dim3(256), 0, stream, count, rows, ids, table_rows, hist, rows_out, ids_out, k_out);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -2453,7 +2507,7 @@ int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const i
 // Forward flavour: ws int32 [3*M + n + 4]; ws[2] = 1 when row 0 of the (bf16) table is not all zero -> every row live;
 // ws[4 + 3M + i] = bit mask of sequence i (L <= 32): bit t set = token t is live.
 int nr_launch_compact_rows_fwd(const int32_t* ids, int M, int n, int L, const void* table_row0, int cols, int32_t* ws,
-                               hipStream_t stream) {
+                               hipStream_t stream, int32_t* posmap) {
   NR_CHECK_ARG(ids != nullptr && ws != nullptr && M > 0 && table_row0 != nullptr && n * L == M, "compact_rows_fwd: bad arguments");
   NR_CHECK_HIP(hipMemsetAsync(ws, 0, 4 * sizeof(int32_t), stream));
   NrProfScope ps(stream, "compact_rows[M=%d]", M);
@@ -2461,7 +2515,7 @@ int nr_launch_compact_rows_fwd(const int32_t* ids, int M, int n, int L, const vo
   if (L <= 32)
     hipLaunchKernelGGL(title_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ids, n, L, (const int32_t*)(ws + 2),
                        reinterpret_cast<uint32_t*>(ws + 4 + 3 * (size_t)M));
-  hipLaunchKernelGGL(compact_rows_kernel<true>, dim3((M + 1023) / 1024), dim3(256), 0, stream, ids, 1, M, ws, (const int32_t*)(ws + 2));
+  hipLaunchKernelGGL(compact_rows_kernel<true>, dim3((M + 1023) / 1024), dim3(256), 0, stream, ids, 1, M, ws, (const int32_t*)(ws + 2), posmap);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -2527,6 +2581,24 @@ int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, i
     hipLaunchKernelGGL((rows_materialize_kernel<bf16_t, ROWS_GATHER>), dim3((unsigned)grid), dim3(256), 0, stream, A, (bf16_t*)out, ldo, M, K);
   else
     hipLaunchKernelGGL((rows_materialize_kernel<float, ROWS_GATHER>), dim3((unsigned)grid), dim3(256), 0, stream, A, (float*)out, ldo, M, K);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_launch_gather_live_rows(int dtype, const RowSrc& A, void* out, int ldo, int Mmax, int K, const int32_t* count, const int32_t* rows,
+                               const int32_t* ids, hipStream_t stream) {
+  const int ch = nr_chunk(dtype);
+  NR_CHECK_ARG(A.kind == ROWS_GATHER && K % ch == 0 && ldo % ch == 0 && ldo >= K && A.ld >= K && count && rows && ids && out,
+               "gather_live_rows: bad arguments");
+  NrProfScope ps(stream, "rows_materialize_live[%s,Mmax=%d,K=%d]", dtype == NR_BF16 ? "bf16" : "f32", Mmax, K);
+  const size_t total = (size_t)Mmax * (K / ch);
+  size_t grid = (total + 256 * 4 - 1) / (256 * 4);
+  if (grid > 256 * 16) grid = 256 * 16;              // 16 workgroups of 4 waves per CU: 64 row chains in flight per CU
+  if (grid < 1) grid = 1;
+  if (dtype == NR_BF16)
+    hipLaunchKernelGGL(gather_live_rows_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, stream, A, (bf16_t*)out, ldo, K, count, rows, ids);
+  else
+    hipLaunchKernelGGL(gather_live_rows_kernel<float>, dim3((unsigned)grid), dim3(256), 0, stream, A, (float*)out, ldo, K, count, rows, ids);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -2872,9 +2944,25 @@ int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, si
 }
 
 // out: int32 [4 + n]: out[0] = count, out[4 ..] = sequence numbers
-int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream) {
+int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream, int reach) {
   NR_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream));
-  hipLaunchKernelGGL(seq_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, title_nz, tmask, n, 32 / L + 2, out, out + 4);
+  hipLaunchKernelGGL(seq_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, title_nz, tmask, n, reach >= 0 ? reach : 32 / L + 2, out,
+                     out + 4);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+// rows *count .. roundup32(*count) of a [Mmax, ld] bf16 buffer become zeros (compact row storage: the weight-gradient GEMM
+// contracts whole 32-row slabs of the live rows)
+namespace {
+__global__ __launch_bounds__(256) void zero_tail_rows_kernel(uint4* __restrict__ buf, int chunks, const int32_t* __restrict__ count, int Mmax) {
+  const int n = *count, end = min(Mmax, (n + 31) / 32 * 32);
+  for (int u = threadIdx.x; u < (end - n) * chunks; u += 256) buf[(size_t)n * chunks + u] = make_uint4(0, 0, 0, 0);
+}
+}  // namespace
+int nr_launch_zero_tail_rows(void* buf, int ld, const int32_t* count, int Mmax, hipStream_t stream) {
+  NR_CHECK_ARG(buf != nullptr && count != nullptr && ld % 8 == 0 && (((uintptr_t)buf) & 15) == 0, "zero_tail_rows: bad arguments");
+  hipLaunchKernelGGL(zero_tail_rows_kernel, dim3(1), dim3(256), 0, stream, (uint4*)buf, ld / 8, count, Mmax);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -2907,6 +2995,14 @@ int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, flo
   return tn3::launch(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap);
 }
 bool nr_gemm_tn_slabs_ok(int ldc, int ldx, int M, int N, int K) { return tn3::eligible(ldc, ldx, M, N, K); }
+// dW += dC^T . X over the first *row_count rows of two dense operands that hold at most Mmax rows (compact row storage: rows
+// row_count .. roundup32(row_count) must be zero in X and finite in dC).  No bias gradient: its rows are not all here.
+int nr_launch_gemm_tn_counted(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, int Mmax, int N, int K, int Nstore,
+                              int Kstore, const int32_t* row_count, hipStream_t stream) {
+  NR_CHECK_ARG(tn3::eligible(ldc, ldx, Mmax, N, K) && row_count != nullptr, "gemm_tn_counted: shape not eligible");
+  NrProfScope ps(stream, "gemm_tn3_rows[bf16,Mmax=%d,N=%d,K=%d,gap=0]", Mmax, N, K);
+  return tn3::launch(dC, ldc, X, ldx, dW, ldw, nullptr, Mmax, N, K, Nstore, Kstore, stream, nullptr, row_count, 0);
+}
 
 int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db, int M, int N,
                       int K, int Nstore, int Kstore, hipStream_t stream) {
