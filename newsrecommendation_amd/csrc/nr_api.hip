@@ -46,7 +46,7 @@ struct OptDef { const char* name; int def; };
 const OptDef g_opt_defs[NR_OPT_COUNT] = {
     {"NO_SLABS", 0},   {"NO_ATTN_SKIP", 0}, {"SIDE_STREAM", 0}, {"ATTN_OLD", 0},  {"ATTN_VALU", 0},   {"NO_PAD_SUB", 0},
     {"NO_FUSED_FWD", 0}, {"NO_TN3", 0},     {"TN_V1", 0},       {"TN3_ROUNDS", 0}, {"TN3_WK", 0},      {"TN3_NI", 0},
-    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}, {"NO_ROW_SUB", 0}, {"ATTN_BWD_OCC4", 0}, {"NT_ABLATE", 0}, {"NT_WREG", 1}, {"NO_SCATTER_SORT", 0}, {"TN3_MIN_M", 16384}, {"NO_COMPACT_ROWS", 0}};
+    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}, {"NO_ROW_SUB", 0}, {"ATTN_BWD_OCC4", 0}, {"NT_ABLATE", 0}, {"NT_WREG", 1}, {"NO_SCATTER_SORT", 0}, {"TN3_MIN_M", 16384}, {"NO_COMPACT_ROWS", 0}, {"NO_POOL_FUSED", 0}, {"POOL_ABLATE", 0}};
 std::atomic<int> g_opt[NR_OPT_COUNT];
 std::once_flag g_opt_once;
 void opt_init() {
@@ -926,6 +926,11 @@ int nr_additive_pool_fwd(const nr_pool_desc* d, void* e, float* alpha, float* ou
   NR_CHECK_ARG(e && alpha && out && ld_out >= d->N, "additive_pool_fwd: null output / ld_out");
   NR_DEVICE_GUARD(stream, out);
   hipStream_t s = (hipStream_t)stream;
+  // title-level shapes (L <= 32 tokens, N ~ 400, q <= 256, bf16): fc1 + tanh + fc2 + softmax + weighted sum in one pass over x
+  if (nr_pool_fused_fwd_ok(d->dtype, d->n, d->L, d->N, d->q, d->ldw1) && ((((uintptr_t)d->x) | ((uintptr_t)d->w1) | ((uintptr_t)e)) & 15) == 0 &&
+      d->N % 8 == 0 && d->mask == nullptr)
+    return nr_launch_pool_fused_fwd(d->x, d->N, d->w1, d->ldw1, d->b1, d->w2, d->b2, d->mask, e, d->q, alpha, out, ld_out, d->n, d->L, d->N, d->q,
+                                    d->seq_needed, s);
   RowSrc A = dense_rows(d->x, d->N, d->N);
   EpiArgs ep = store_epi(e, d->q, d->dtype, d->b1, 1);
   ep.seq_nz = d->seq_needed; ep.L = d->L;          // row tiles made of unneeded sequences only are not computed (e stays unwritten)

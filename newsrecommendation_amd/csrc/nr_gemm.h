@@ -95,6 +95,11 @@ int nr_launch_zero_tail_rows(void* buf, int ld, const int32_t* count, int Mmax, 
 int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K,
                             int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream, int xgap = 0);
 bool nr_gemm_tn_slabs_ok(int ldc, int ldx, int M, int N, int K);
+// fused additive-pooling forward (fc1 + tanh + fc2 + softmax + weighted sum), title-level shapes; see pool_fused_fwd_kernel
+int nr_pool_fused_fwd_ok(int dtype, int n, int L, int N, int q, int ldw1);
+int nr_launch_pool_fused_fwd(const void* x, int ldx, const void* w1, int ldw1, const float* b1, const float* w2, const float* b2,
+                             const float* mask, void* e, int lde, float* alpha, float* out, int ld_out, int n, int L, int N, int q,
+                             const int32_t* needed, hipStream_t stream);
 int nr_launch_gemm_tn_counted(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, int Mmax, int N, int K, int Nstore,
                               int Kstore, const int32_t* row_count, hipStream_t stream);
 // live rows only, in live-list order (count / rows / ids of nr_launch_compact_rows_fwd), zero-filled to a multiple of 32 rows

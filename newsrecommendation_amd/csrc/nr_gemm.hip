@@ -1767,6 +1767,296 @@ int launch_nt_wreg_m(const RowSrc& A, const void* B, int ldb, int M, int N, int 
   return NR_OK;
 }
 
+// =========================================================================================
+// Fused additive-attention pooling FORWARD (src/model/model_utils.py:21-30) for sequences of L <= 32 tokens:
+//   e = tanh(x W1^T + b1) -> a = exp(e w2 + b2) (* mask) / (sum + 1e-8) -> out = sum_l a_l x_l
+// in ONE pass over x.  The unfused path ran the weights-in-registers fc1 GEMM (x in, e out) and then pool_core_fwd
+// (x and e in again): 0.14 + 0.16 ms and 0.57 GB of re-reads per step at the news level.
+//
+// Built on the weights-in-registers GEMM above (8 waves, W1 resident in registers, 2 column tiles per wave, activation rows
+// through an LDS ring filled by LDS-DMA), with a stage = ONE SEQUENCE (32 rows from row seq * L: the L real ones and 32 - L
+// rows of the next sequence that only ride along), and a software pipeline with one barrier per step k:
+//   S0  issue the DMAs of sequence k + NS - 2                              (slot (k - 2) % NS, last read in step k - 1)
+//   S1  sequence k - 2: out = sum over the 8 row groups of sRed[(k - 2) % 2]                       -> global (fp32)
+//   S2  sequence k - 1: logits = sum of the 8 waves' partial dots sPart[(k - 1) % 2] + b2 -> softmax weights (every wave,
+//       32 lanes) -> alpha (global) -> this wave's 4 rows of the weighted sum over the x rows STILL IN the ring -> sRed
+//   S3  sequence k    : MFMAs -> tanh -> e (global, bf16: the backward needs it) -> partial dots with w2 -> sPart[k % 2]
+// Vector-memory bookkeeping is static as above: every wave issues PW DMAs + S + 2 stores per step.
+// Sequences nobody needs (flags == 0) get zeros in out / alpha from the prologue and are left out of the walk.
+// =========================================================================================
+struct PoolFusedArgs {
+  const bf16_t* x; int ldx;          // [n * L, ldx]
+  const bf16_t* w1; int ldw1;        // [q, ldw1] packed (zero beyond N up to a multiple of 32)
+  const float* b1; const float* w2; const float* b2;
+  bf16_t* e; int lde;                // [n * L, lde] out
+  float* alpha;                      // [n * L] out
+  float* out; int ld_out;            // [n, ld_out] out
+  const int32_t* needed;             // [n] or null
+  int n, L, N, q;
+  int ablate;                        // NR_OPT_POOL_ABLATE (measurement only)
+};
+
+template <int KS>
+struct PoolFusedCfg {
+  static constexpr int NW = 8, TPW = 2, RT = 2, R = 32;
+  static constexpr int APIECES = RT * KS, PW = (APIECES + NW - 1) / NW, STAGE = APIECES * 1024;
+  static constexpr int NS = 4;
+  static constexpr int S = RT;                                         // e stores per wave and step (two tiles paired per store)
+  static constexpr int NCOL = KS * 32;                                 // columns of x the ring holds (>= N)
+  static constexpr int DUMP = NS * STAGE, BIAS = DUMP + NW * 1024;     // per-wave dump piece | bias [256] fp32
+  static constexpr int PART = BIAS + 1024;                             // sPart [2][NW][32] fp32
+  static constexpr int RED = PART + 2 * NW * 32 * 4;                   // sRed [2][NW][NCOL] fp32
+  static constexpr int LIST = RED + 2 * NW * NCOL * 4;                 // the walk: sequence numbers
+  static constexpr int STEADY = PW + 2 * (S + 2);                      // ops younger than stage k's DMAs at the top of step k
+  static_assert(STEADY <= 62, "vmcnt is a 6-bit counter");
+};
+
+template <int KS>
+__global__ __launch_bounds__(512) void pool_fused_fwd_kernel(PoolFusedArgs a, int max_steps) {
+  using Cfg = PoolFusedCfg<KS>;
+  constexpr int NW = Cfg::NW, TPW = Cfg::TPW, RT = Cfg::RT, R = Cfg::R, NS = Cfg::NS, PW = Cfg::PW, STAGE = Cfg::STAGE, NCOL = Cfg::NCOL;
+  constexpr int APIECES = Cfg::APIECES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, g = lane >> 4;
+  const int prow = lane >> 2, c8 = ((lane & 3) ^ swzP(prow)) * 8;
+  const int L = a.L, N = a.N, q = a.q, M = a.n * a.L;
+  float* sBias = reinterpret_cast<float*>(smem + Cfg::BIAS);
+  float* sPart = reinterpret_cast<float*>(smem + Cfg::PART);
+  float* sRed = reinterpret_cast<float*>(smem + Cfg::RED);
+  int* sList = reinterpret_cast<int*>(smem + Cfg::LIST);
+
+  // ---- the walk: this workgroup's needed sequences, in order; the others get their zeros here
+  const int G = gridDim.x, b0 = blockIdx.x;
+  int nsteps = b0 < a.n ? (a.n - b0 + G - 1) / G : 0;
+  if (a.needed != nullptr) {
+    __shared__ int sCnt[NW + 1];
+    const int cand = nsteps;
+    int run = 0;
+    for (int base = 0; base < cand; base += 512) {
+      const int c = base + tid, sq = b0 + c * G;
+      const bool live = c < cand && a.needed[sq] != 0;
+      const uint64_t bal = __ballot(live);
+      if (lane == 0) sCnt[wid] = __popcll(bal);
+      __syncthreads();
+      int before = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const int cw = sCnt[w];
+        before += w < wid ? cw : 0;
+        total += cw;
+      }
+      if (live) sList[run + before + __popcll(bal & ((1ull << lane) - 1ull))] = sq;
+      run += total;
+      __syncthreads();
+    }
+    // zeros for the sequences left out: a wave per sequence
+    for (int c = wid; c < cand; c += NW) {
+      const int sq = b0 + c * G;
+      if (a.needed[sq] != 0) continue;                   // wave-uniform
+      if (lane < L) a.alpha[(size_t)sq * L + lane] = 0.f;
+      for (int col = lane; col < N; col += 64) a.out[(size_t)sq * a.ld_out + col] = 0.f;
+    }
+    nsteps = run;
+  } else {
+    for (int c = tid; c < nsteps; c += 512) sList[c] = b0 + c * G;
+  }
+  if (nsteps == 0) return;
+
+  // ---- W1 slice of this wave (2 column tiles x K), w2 of the lane's 8 columns, bias of all columns
+  const int wcol0 = wid * TPW * 16;
+  bf16x8 bfr[TPW][KS];
+  float w2r[TPW][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int nrow = min(wcol0 + t * 16 + fr, q - 1);
+    const bf16_t* brow = a.w1 + (size_t)nrow * a.ldw1 + 8 * g;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) bfr[t][s2] = *reinterpret_cast<const bf16x8*>(brow + 32 * s2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = wcol0 + t * 16 + 4 * g + r;
+      w2r[t][r] = col < q ? a.w2[col] : 0.f;             // columns beyond q add nothing to the logit
+    }
+  }
+  for (int c = tid; c < NW * TPW * 16; c += 512) sBias[c] = c < q ? a.b1[c] : 0.f;
+  const float b2 = a.b2[0];
+  __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): nothing of the prologue is carried into the loop
+  __syncthreads();                                       // list + bias complete
+
+  const uint32_t dump_lds = lds0 + Cfg::DUMP + wid * 1024;
+  // stage issue: every wave exactly PW DMAs (surplus ones and the steps past the end into its dump piece)
+  auto issue_stage = [&](int kk) {
+    const uint32_t slot = lds0 + (kk % NS) * STAGE;
+    const bool real = kk < nsteps;
+    const int row0 = real ? sList[kk] * L : 0;
+    const bf16_t* rowp[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) rowp[i] = a.x + (size_t)min(row0 + 16 * i + prow, M - 1) * a.ldx + c8;
+#pragma unroll
+    for (int u = 0; u < PW; ++u) {
+      const int p = wid + NW * u;                        // wave-uniform
+      if (real && p < APIECES) {
+        const int i = p / KS, s2 = p - i * KS;
+        const bf16_t* rp = i == 0 ? rowp[0] : rowp[1];
+        dma16(rp + min(32 * s2, N - 8 - c8), slot + p * 1024);   // (K tail: re-read a valid chunk; W1 is zero there)
+      } else {
+        dma16(a.x + c8, dump_lds);
+      }
+    }
+  };
+  uint4* dump_g = g_nt_dump + wid * 64 + lane;
+  const int offA = fr * 64 + ((g ^ swzP(fr)) << 4);
+  // weighted-sum geometry (S2): lane = 16-byte column chunk (0 .. N/8), wave = row group (rows wid, wid + 8, ...)
+  const int cc = lane, ccp = cc >> 2, ccs = cc & 3;
+  const bool cc_ok = cc * 8 < N;
+
+#pragma unroll 1
+  for (int kk = 0; kk < NS - 2; ++kk) issue_stage(kk);
+
+  // 32-lane all-reduce of a value held identically by lanes l and l + 32: four DPP row rotations + one cross-row exchange
+  auto sum32 = [&](float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v + __shfl_xor(v, 16, 64);
+  };
+  // S1: sequence k - 2 -> out
+  auto phase_out = [&](int k) {
+    const int kf = k - 2;
+    float* dst = reinterpret_cast<float*>(dump_g);
+    if (kf >= 0 && kf < nsteps && tid < N && !(a.ablate & 4)) {
+      const float* red = sRed + (kf & 1) * NW * NCOL + tid;
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < NW; ++r) v += red[r * NCOL];
+      *(a.out + (size_t)sList[kf] * a.ld_out + tid) = v;
+    } else {
+      *dst = 0.f;                                                              // same store count in every wave
+    }
+  };
+  // S2: sequence k - 1 -> alpha, this wave's rows of the weighted sum
+  auto phase_alpha = [&](int k) {
+    const int kp = k - 1;
+    const bool real = kp >= 0 && kp < nsteps;
+    const int sq = real ? sList[kp] : 0;
+    const float* part = sPart + (kp & 1) * NW * 32 + (lane & 31);
+    float al = 1.f;
+    if (!(a.ablate & 2)) {
+      // a_l = exp(s_l) / (sum + 1e-8), exactly as src/model/model_utils.py:23-30 writes it (no maximum is subtracted there
+      // either; |s| <= |w2|_1 + |b2| because |e| <= 1)
+      float sl = b2;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sl += part[w * 32];
+      const float ex = (lane & 31) < L ? __expf(sl) : 0.f;
+      al = ex / (sum32(ex) + 1e-8f);
+    }
+    float* adst = (real && wid == 0 && lane < L) ? a.alpha + (size_t)sq * L + lane : reinterpret_cast<float*>(dump_g);
+    *adst = al;
+    if (real && !(a.ablate & 1)) {
+      const char* st = smem + (kp % NS) * STAGE;
+      // lane = 16-byte column chunk (clamped: the surplus lanes read chunk 0 and drop it), wave = rows wid, wid + 8, ...
+      const int ccr = cc_ok ? cc : 0;
+      bf16x8 xv[R / NW];
+#pragma unroll
+      for (int j = 0; j < R / NW; ++j) {
+        const int m = min(wid + NW * j, L - 1);            // rows L .. 31 belong to the NEXT sequence (maybe unwritten memory): never read
+        xv[j] = *reinterpret_cast<const bf16x8*>(st + ((m >> 4) * KS + (ccr >> 2)) * 1024 + (m & 15) * 64 + (((ccr & 3) ^ swzP(m & 15)) << 4));
+      }
+      float acc[8];
+#pragma unroll
+      for (int e2 = 0; e2 < 8; ++e2) acc[e2] = 0.f;
+#pragma unroll
+      for (int j = 0; j < R / NW; ++j) {
+        const int m = wid + NW * j;                          // wave-uniform
+        const float am = m < L ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, al), m < L ? m : 0)) : 0.f;
+#pragma unroll
+        for (int e2 = 0; e2 < 8; ++e2) acc[e2] = fmaf(am, (float)xv[j][e2], acc[e2]);
+      }
+      if (cc_ok) {
+        float* rd = sRed + ((kp & 1) * NW + wid) * NCOL + cc * 8;
+        *reinterpret_cast<f32x4*>(rd) = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(rd + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+      }
+    }
+  };
+  // S3: sequence k -> e, partial logits
+  auto phase_gemm = [&](int k) {
+    const bool real = k < nsteps;
+    const int row0 = real ? sList[k] * L : 0;
+    const char* st = smem + (k % NS) * STAGE;
+    f32x4 acc[RT][TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + (wid * TPW + t) * 16 + 4 * g);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) acc[i][t] = bv;
+    }
+    if (real && wcol0 < q && !(a.ablate & 8)) {                              // wave-uniform
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(st + (i * KS + s2) * 1024 + offA);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][s2], af, acc[i][t], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const int ml = 16 * i + fr;                                            // row inside the sequence
+      const bool rok = real && ml < L;
+      bf16_t* crow = a.e + (size_t)(row0 + ml) * a.lde;
+      float pd = 0.f;
+      uint2 pk[TPW];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float th = (a.ablate & 16) ? acc[i][t][r] : 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * acc[i][t][r]) + 1.f);
+          o[r] = (bf16_t)th;
+          pd = fmaf((float)o[r], w2r[t][r], pd);                              // the logit sees e as the backward will (bf16)
+        }
+        pk[t] = __builtin_bit_cast(uint2, o);
+      }
+      const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+      const int col = wcol0 + (g & 1) * 16 + (g >> 1) * 8;
+      uint4* dst = (rok && col + 8 <= q) ? reinterpret_cast<uint4*>(crow + col) : dump_g;
+      *dst = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      pd += __shfl_xor(pd, 16, 64);
+      pd += __shfl_xor(pd, 32, 64);
+      if (g == 0) sPart[((k & 1) * NW + wid) * 32 + ml] = pd;
+    }
+  };
+
+#pragma unroll 1
+  for (int k = 0; k < nsteps + 2; ++k) {
+    // stage k landed: younger than its DMAs are the stores of steps k-2, k-1 and the DMAs of step k-1
+    if (k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::STEADY) : "memory");
+    else wait_vmcnt_le(k == 0 ? (NS - 3) * PW : PW + (Cfg::S + 2));
+    __builtin_amdgcn_s_barrier();
+    issue_stage(k + NS - 2);                                                  // S0
+    // The three phases of a step touch three different sequences and disjoint LDS buffers: any order is legal.  The two waves
+    // of a SIMD (w and w + 4) take opposite orders, so one runs its MFMAs while the other is in its VALU / LDS phases
+    // (MI355X_MICROARCH.md, "Two waves that run the SAME program with one barrier per block: try a stagger")
+    if (wid < NW / 2) {
+      phase_gemm(k);
+      phase_out(k);
+      phase_alpha(k);
+    } else {
+      phase_out(k);
+      phase_alpha(k);
+      phase_gemm(k);
+    }
+  }
+}
+
 template <int EPI, int NT16, bool PK, int WM>
 int launch_nt_dma_w(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
   constexpr int DBM = 64 * WM, NP = DBM / 16 + NT16, STAGE = NP * 1024, NS = dma_ring_stages(STAGE, WM);
@@ -2581,6 +2871,42 @@ int nr_launch_rows_materialize(int dtype, const RowSrc& A, void* out, int ldo, i
     hipLaunchKernelGGL((rows_materialize_kernel<bf16_t, ROWS_GATHER>), dim3((unsigned)grid), dim3(256), 0, stream, A, (bf16_t*)out, ldo, M, K);
   else
     hipLaunchKernelGGL((rows_materialize_kernel<float, ROWS_GATHER>), dim3((unsigned)grid), dim3(256), 0, stream, A, (float*)out, ldo, M, K);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_pool_fused_fwd_ok(int dtype, int n, int L, int N, int q, int ldw1) {
+  return !nr_opt(NR_OPT_NO_POOL_FUSED) && dtype == NR_BF16 && L >= 24 && L <= 32 && N > 384 && N <= 416 && N % 8 == 0 && q >= 8 && q <= 256 &&
+         q % 8 == 0 && ldw1 >= 416 && (long)n * L >= 4096;
+}
+
+int nr_launch_pool_fused_fwd(const void* x, int ldx, const void* w1, int ldw1, const float* b1, const float* w2, const float* b2,
+                             const float* mask, void* e, int lde, float* alpha, float* out, int ld_out, int n, int L, int N, int q,
+                             const int32_t* needed, hipStream_t stream) {
+  constexpr int KS = 13;
+  using Cfg = PoolFusedCfg<KS>;
+  NR_CHECK_ARG(nr_pool_fused_fwd_ok(NR_BF16, n, L, N, q, ldw1) && ldx >= N && ldx % 8 == 0 && lde >= q && lde % 8 == 0 &&
+                   ((((uintptr_t)x) | ((uintptr_t)w1) | ((uintptr_t)e)) & 15) == 0 && mask == nullptr,
+               "pool_fused_fwd: shape / alignment not eligible (and no mask on this path)");
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, c = 0;
+    NR_CHECK_HIP(hipGetDevice(&dev));
+    NR_CHECK_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = c >= 8 ? c : 256;
+  }
+  const int grid = n < cus ? n : cus;                    // one persistent workgroup per CU
+  const int max_steps = (n + grid - 1) / grid;
+  const size_t smem = (size_t)Cfg::LIST + (size_t)(max_steps + 8) * sizeof(int);
+  NR_CHECK_ARG(smem <= 160 * 1024, "pool_fused_fwd: %d sequences per workgroup do not fit the LDS list", max_steps);
+  PoolFusedArgs a;
+  a.x = (const bf16_t*)x; a.ldx = ldx; a.w1 = (const bf16_t*)w1; a.ldw1 = ldw1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+  a.e = (bf16_t*)e; a.lde = lde; a.alpha = alpha; a.out = out; a.ld_out = ld_out; a.needed = needed; a.n = n; a.L = L; a.N = N; a.q = q;
+  a.ablate = nr_opt(NR_OPT_POOL_ABLATE);
+  auto kern = pool_fused_fwd_kernel<KS>;
+  NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  NrProfScope ps(stream, needed ? "pool_fused_fwd_needed[bf16,n=%d,L=%d,N=%d,q=%d]" : "pool_fused_fwd[bf16,n=%d,L=%d,N=%d,q=%d]", n, L, N, q);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a, max_steps);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }

@@ -190,3 +190,64 @@ def test_sorted_scatter_is_bit_identical_to_batch_order_in_deterministic_mode():
         ops.set_deterministic(False)
     assert torch.equal(a, a2)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,L,q", [(160, 30, 200), (211, 24, 200), (137, 32, 200), (150, 30, 136), (2048, 30, 200)])
+@pytest.mark.parametrize("flags", ["none", "mixed", "all_dead"])
+def test_fused_pooling_forward_against_the_two_kernel_path(n, L, q, flags):
+    """pool_fused_fwd_kernel (round 3): fc1 + tanh + fc2 + softmax + weighted sum in one pass over x, a stage = one sequence
+    (32 rows: the L real ones + 32 - L rows of the NEXT sequence riding along), software-pipelined over three sequences.
+    Against the fc1 GEMM + pool_core_fwd pair (`NO_POOL_FUSED` = 1) and against fp64: out, alpha-dependent gradients and e-
+    dependent gradients (the backward reads the e and alpha the forward wrote).  The x rows of unneeded sequences hold 1e30:
+    they ride along in their neighbours' stages (and n * L is no multiple of 32: the last stage is clamped) and must not leak.
+    Sequence counts that leave workgroups with 0, 1, 2 and many steps; q below a full column group."""
+    g = torch.Generator(device=DEV).manual_seed(n * L + q)
+    N = 400
+    assert n * L >= 4096
+    x = _bf(torch.randn(n, L, N, device=DEV, generator=g) * 0.5)
+    w1 = (torch.randn(q, N, device=DEV, generator=g) * 0.05).requires_grad_(True)
+    b1 = (torch.randn(q, device=DEV, generator=g) * 0.05).requires_grad_(True)
+    w2 = (torch.randn(1, q, device=DEV, generator=g) * 0.1).requires_grad_(True)
+    b2 = (torch.randn(1, device=DEV, generator=g) * 0.1).requires_grad_(True)
+    if flags == "none":
+        needed, keep = None, torch.ones(n, dtype=torch.bool, device=DEV)
+    else:
+        keep = torch.rand(n, device=DEV, generator=g) < (0.55 if flags == "mixed" else -1.0)
+        needed = ops.needed_flags(keep)
+        x[~keep] = 1e30        # (finite: at these sizes the backward's dense dW1 = dpre^T . x multiplies these rows by exact zeros)
+    gout = torch.randn(n, N, device=DEV, generator=g) * keep.float().unsqueeze(1)
+
+    def run():
+        xx = x.clone().requires_grad_(True)
+        for p in (w1, b1, w2, b2):
+            p.grad = None
+        _lib.prof_enable(1)
+        try:
+            _lib.prof_collect()
+            out = ops.additive_pool(xx, w1, b1, w2, b2, ops.NR_BF16, mask=None, needed=needed)
+            labels = set(_lib.prof_collect().keys())
+        finally:
+            _lib.prof_enable(0)
+        out.backward(gout)
+        return labels, (out.detach(), xx.grad.detach().float()[keep], w1.grad.clone(), b1.grad.clone(), w2.grad.clone(), b2.grad.clone())
+
+    lab1, got = run()
+    with _opt("NO_POOL_FUSED", 1):
+        lab0, old = run()
+    assert any(l.startswith("pool_fused_fwd") for l in lab1) and not any(l.startswith("pool_core_fwd") for l in lab1)
+    assert any(l.startswith("pool_core_fwd") for l in lab0) and not any(l.startswith("pool_fused_fwd") for l in lab0)
+    for nm, a, b in zip(["out", "dx", "dw1", "db1", "dw2", "db2"], got, old):
+        assert torch.isfinite(a).all(), nm
+        if a.numel() == 0:
+            continue
+        scale = b.abs().max().item()
+        tol = (2.0 ** -7 if nm in ("out", "dx") else 2e-3) * scale + 1e-6
+        if nm == "db2":      # analytically 0 (the softmax weights sum to 1: a shift of every logit changes nothing): rounding noise
+            tol = 1e-4 * old[4].abs().max().item() + 1e-6
+        assert (a - b).abs().max().item() <= tol, (nm, (a - b).abs().max().item(), scale)
+    if keep.any():
+        xr = torch.where(keep[:, None, None], x, torch.zeros_like(x))
+        ref = _pool_ref(xr, _bf(w1.detach()), b1.detach(), w2.detach(), b2.detach(), None)
+        assert (got[0][keep].double() - ref[keep]).abs().max().item() <= 1e-2 * ref[keep].abs().max().item() + 1e-4
+    if (~keep).any():
+        assert got[0][~keep].abs().max().item() == 0.0
