@@ -166,6 +166,11 @@ typedef struct {
                          backward, dx / table gradient) ; 2: only dw_qkv / db_qkv, after a phase-1 call with the same
                          descriptor and row_ws.  The split lets a data-parallel host start the all-reduce of the (large)
                          table gradient while the weight-gradient GEMM still runs.  Not in deterministic mode.      */
+  int y_far_unwritten; /* nr_mhsa_fwd only, with seq_needed: nonzero = the y rows of an unneeded sequence need to be ZEROS only when
+                         a needed sequence lies within 32 / L + 2 sequences of it (a 32-row slab of a weight-gradient GEMM can then
+                         reach them); farther ones may stay UNWRITTEN.  For callers whose only consumer of y is
+                         nr_additive_pool_fwd / _bwd with the same flags on a shape for which nr_pool_contracts_slabs() says 1
+                         (it never reads those rows); 0.3 GB of zero stores per step at the news level otherwise.          */
 } nr_mhsa_desc;
 
 /* qkv: [n*L, 3N] dtype (saved for backward); y: [n*L, N] dtype.
@@ -255,6 +260,10 @@ typedef struct {
                          flags: the pooled gradient of such a sequence is zero by contract, its dpre / dx rows are written as zeros
                          and its e rows are never read                                                                       */
 } nr_pool_desc;
+/* 1 when nr_additive_pool_bwd contracts only the 32-row slabs that touch a sequence with a non-zero pooled gradient for this
+ * descriptor (n, L, N, q, dtype are read): it then never reads x rows farther than 32 / L + 2 sequences from such a sequence
+ * (see nr_mhsa_desc.y_far_unwritten).  0: its weight-gradient GEMM reads every row of x.                                  */
+int nr_pool_contracts_slabs(const nr_pool_desc* d);
 /* Bytes of the `partial` workspace of nr_additive_pool_bwd. */
 size_t nr_pool_workspace_bytes(const nr_pool_desc* d);
 /* After nr_additive_pool_bwd (bf16, L <= 32, rows a multiple of 32): the [n] int32 flags inside `partial` that say which

@@ -29,7 +29,8 @@ class MhsaDesc(C.Structure):
                 ("p_in", C.c_float), ("seed_in", C.c_uint32), ("p_out", C.c_float), ("seed_out", C.c_uint32),
                 ("mask", C.c_void_p), ("w_qkv", C.c_void_p), ("ldw", C.c_int), ("b_qkv", C.c_void_p),
                 ("x_rows", C.c_void_p), ("ld_rows", C.c_int), ("row_ws", C.c_void_p), ("row_ws_bytes", C.c_size_t),
-                ("table_rows", C.c_int), ("proj_table", C.c_void_p), ("seq_needed", C.c_void_p), ("seq_nz", C.c_void_p), ("row_ws_ready", C.c_int), ("bwd_phase", C.c_int)]
+                ("table_rows", C.c_int), ("proj_table", C.c_void_p), ("seq_needed", C.c_void_p), ("seq_nz", C.c_void_p), ("row_ws_ready", C.c_int), ("bwd_phase", C.c_int),
+                ("y_far_unwritten", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -74,6 +75,7 @@ SIGNATURES = {
     "nr_mhsa_workspace_bytes": [C.POINTER(MhsaDesc)],
     "nr_conv_workspace_bytes": [C.POINTER(ConvDesc)],
     "nr_pool_workspace_bytes": [C.POINTER(PoolDesc)],
+    "nr_pool_contracts_slabs": [C.POINTER(PoolDesc)],
     "nr_pool_seq_flags": [C.POINTER(PoolDesc), _vp],
     "nr_linear_workspace_bytes": [C.POINTER(LinearDesc)],
     "nr_sdpa_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u32, _vp],

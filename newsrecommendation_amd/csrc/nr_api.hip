@@ -452,6 +452,9 @@ size_t nr_mhsa_workspace_bytes(const nr_mhsa_desc* d) {
 size_t nr_conv_workspace_bytes(const nr_conv_desc* d) {
   return (d == nullptr || d->n < 0 || d->T < 1) ? 0 : conv_ws_elems(d->n, d->T) * sizeof(int32_t);
 }
+int nr_pool_contracts_slabs(const nr_pool_desc* d) {
+  return (d != nullptr && d->n > 0 && d->L >= 1 && d->q >= 1 && dtype_ok(d->dtype) && pool_has_flags(d)) ? 1 : 0;
+}
 size_t nr_pool_workspace_bytes(const nr_pool_desc* d) {
   return (d == nullptr || d->n < 0 || d->L < 1 || d->q < 1) ? 0 : pool_ws_elems(d->n, d->L, d->q) * sizeof(float);
 }
@@ -643,7 +646,9 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   const int32_t* fwd_list = nullptr;
   if (d->seq_needed != nullptr && tmask != nullptr && ((size_t)d->L * N * nr_elt_size(d->dtype)) % 16 == 0 && (((uintptr_t)y) & 15) == 0) {
     int32_t* lw = d->row_ws + W.seq;
-    if ((rc = nr_launch_needed_list(d->seq_needed, d->n, lw, y, (size_t)d->L * N * nr_elt_size(d->dtype), s))) return rc;
+    if ((rc = nr_launch_needed_list(d->seq_needed, d->n, lw, y, (size_t)d->L * N * nr_elt_size(d->dtype), s,
+                                    d->y_far_unwritten ? 32 / d->L + 2 : -1)))
+      return rc;
     fwd_list = lw;
   }
   return nr_launch_attn(false, d->dtype, qkv, d->mask, y, nullptr, nullptr, d->n, d->L, d->heads, d->d_head,

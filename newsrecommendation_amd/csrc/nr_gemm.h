@@ -88,7 +88,8 @@ int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_
 int nr_launch_title_flags(const void* dy, int n, int L, int N, int32_t* title_nz, hipStream_t stream);
 int nr_launch_row_flags_f32(const float* g, int ld, int N, int n, int32_t* nz, hipStream_t stream);
 int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream);
-int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream);
+// reach >= 0: the y rows of an unneeded sequence are zero-filled only when a needed one lies within `reach` sequences
+int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream, int reach = -1);
 // reach: an all-padding sequence is left out when its own and `reach` neighbours' gradients are zero (-1: 32 / L + 2, the span of a slab)
 int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream, int reach = -1);
 int nr_launch_zero_tail_rows(void* buf, int ld, const int32_t* count, int Mmax, hipStream_t stream);

@@ -3251,20 +3251,27 @@ __global__ __launch_bounds__(256) void needed_list_kernel(const int32_t* __restr
   }
 }
 // one workgroup per unneeded sequence: its rows (chunks16 16-byte pieces) become zeros
-__global__ __launch_bounds__(256) void zero_unneeded_kernel(const int32_t* __restrict__ flags, uint4* __restrict__ y, int chunks16) {
+// reach >= 0: only when a needed sequence lies within `reach` sequences (the others stay unwritten: nobody reads them)
+__global__ __launch_bounds__(256) void zero_unneeded_kernel(const int32_t* __restrict__ flags, uint4* __restrict__ y, int chunks16, int n,
+                                                            int reach) {
   const int seq = blockIdx.x;
   if (flags[seq] != 0) return;
+  if (reach >= 0) {
+    bool near = false;
+    for (int t = max(0, seq - reach) + (int)threadIdx.x; t <= min(n - 1, seq + reach); t += 256) near |= flags[t] != 0;
+    if (!__syncthreads_or(near)) return;
+  }
   uint4* p = y + (size_t)seq * chunks16;
   for (int c = threadIdx.x; c < chunks16; c += 256) p[c] = make_uint4(0, 0, 0, 0);
 }
 }  // namespace
 // out: int32 [4 + n]: out[0] = count, out[4 ..] = the needed sequences; y rows of the others are zero-filled (row_bytes % 16 == 0)
-int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream) {
+int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream, int reach) {
   NR_CHECK_ARG(flags != nullptr && out != nullptr && y != nullptr && seq_bytes % 16 == 0 && (((uintptr_t)y) & 15) == 0, "needed_list: bad arguments");
   NR_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream));
   NrProfScope ps(stream, "needed_list[n=%d]", n);
   hipLaunchKernelGGL(needed_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, flags, n, out, out + 4);
-  hipLaunchKernelGGL(zero_unneeded_kernel, dim3(n), dim3(256), 0, stream, flags, reinterpret_cast<uint4*>(y), (int)(seq_bytes / 16));
+  hipLaunchKernelGGL(zero_unneeded_kernel, dim3(n), dim3(256), 0, stream, flags, reinterpret_cast<uint4*>(y), (int)(seq_bytes / 16), n, reach);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }

@@ -29,7 +29,12 @@ class NewsEncoder(nn.Module):
         history slot): it is returned as zeros without being encoded."""
         p = self.drop_rate if self.training else 0.0
         needed = ops.needed_flags(needed)
-        y = self.multi_head_self_attn.forward_gather(x, self.embedding_matrix.weight, mask=mask, p_in=p, p_out=p, needed=needed)
+        # y feeds the pooling below and nothing else: where its backward contracts live slabs only, the context rows of unneeded
+        # titles far from every needed one are never read and need not even be zero-filled
+        far = needed is not None and ops.pool_contracts_slabs(x.shape[0], x.shape[1], self.attn.att_fc1.in_features,
+                                                              self.attn.att_fc1.out_features, ops.dtype_code(self.attn.compute_dtype))
+        y = self.multi_head_self_attn.forward_gather(x, self.embedding_matrix.weight, mask=mask, p_in=p, p_out=p, needed=needed,
+                                                     far_unwritten=far)
         return self.attn(y, mask, needed=needed)
 
 

@@ -81,8 +81,8 @@ class MultiHeadSelfAttention(nn.Module):
         return ops.mhsa(x, *self._params(), heads=self.n_heads, code=code, mask=mask, p_out=p_out,
                         flat=getattr(self, "_nr_flat", None))
 
-    def forward_gather(self, ids, table, mask=None, p_in=0.0, p_out=0.0, needed=None):
+    def forward_gather(self, ids, table, mask=None, p_in=0.0, p_out=0.0, needed=None, far_unwritten=False):
         """Embedding lookup + dropout + MHSA + dropout in one op: ids int32 [batch, L] into `table` [V, d_model]."""
         code = ops.dtype_code(self.compute_dtype)
         return ops.mhsa(None, *self._params(), heads=self.n_heads, code=code, mask=mask, ids=ids, table=table,
-                        p_in=p_in, p_out=p_out, flat=getattr(self, "_nr_flat", None), needed=needed)
+                        p_in=p_in, p_out=p_out, flat=getattr(self, "_nr_flat", None), needed=needed, far_unwritten=far_unwritten)

@@ -372,7 +372,7 @@ class MHSAFunction(Function):
         w_p = pack(wcat, code)
         mask_c = mask.contiguous().float() if mask is not None else None
         dev = wq.device
-        y = torch.empty(n, L, N, dtype=torch_dtype(code), device=dev)
+        y = _scratch(n, L, N, dtype=torch_dtype(code), device=dev)      # (poisoned in the tests: far unneeded rows may stay unwritten)
         # training with a gather source: keep the gathered + dropped-out rows for the weight-gradient GEMM
         need_bwd = any(ctx.needs_input_grad[:7])
         keep_rows = gather and any(ctx.needs_input_grad[1:7])
@@ -383,6 +383,7 @@ class MHSAFunction(Function):
                           p_in=cfg["p_in"], seed_in=cfg["seed_in"], p_out=cfg["p_out"], seed_out=cfg["seed_out"],
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
                           x_rows=ptr(x_rows), ld_rows=Kp, seq_needed=ptr(cfg.get("needed")),
+                          y_far_unwritten=int(bool(cfg.get("far_unwritten")) and cfg.get("needed") is not None),
                           table_rows=cfg["table_shape"][0] if gather else 0)     # (sizes the id-sort scratch of the backward)
         # scratch for the device-side compaction of non-padding rows (forward: live rows, their ids, padding rows;
         # backward: live slabs, sequence list) -- sized by the library
@@ -486,14 +487,25 @@ def needed_flags(needed):
     return (needed.reshape(-1) != 0).to(torch.int32).contiguous()
 
 
+def pool_contracts_slabs(n: int, L: int, N: int, q: int, code: int) -> bool:
+    """True when the additive-pooling backward of this shape reads only the x rows near sequences with a gradient (its weight
+    gradient contracts live 32-row slabs): the producer of x may then leave far unneeded rows unwritten (mhsa far_unwritten)."""
+    d = _lib.PoolDesc(n=int(n), L=int(L), N=int(N), q=int(q), dtype=int(code))
+    return bool(_lib.lib().nr_pool_contracts_slabs(C.byref(d)))
+
+
 def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int, code: int, mask=None, ids=None, table=None, p_in=0.0, p_out=0.0, flat=None,
-         needed=None):
+         needed=None, far_unwritten=False):
     """Dense: x [n, L, d_model] (compute dtype).  Gather: ids int32 [n, L] + fp32 `table` parameter.
     flat: {"w": [3N, d_model], "b": [3N], "gw", "gb"} views of a flat parameter / gradient bucket (parallel.FlatBucket).
     needed: optional [n] int32 flags (needed_flags): sequences with flag 0 reach the loss through a factor 0 only; their
-    output rows are exact zeros and are not computed (their gradient is zero, so nothing flows back either)."""
+    output rows are exact zeros and are not computed (their gradient is zero, so nothing flows back either).
+    far_unwritten: with `needed`, the output rows of unneeded sequences farther than 32 / L + 2 sequences from every needed
+    one may stay UNWRITTEN (not even zeros) -- only for a caller whose sole consumer is additive_pool with the same flags on
+    a shape for which pool_contracts_slabs() holds."""
     cfg = dict(code=code, heads=heads, p_in=float(p_in), p_out=float(p_out),
-               seed_in=draw_seed() if p_in > 0 else 0, seed_out=draw_seed() if p_out > 0 else 0, needed=needed)
+               seed_in=draw_seed() if p_in > 0 else 0, seed_out=draw_seed() if p_out > 0 else 0, needed=needed,
+               far_unwritten=bool(far_unwritten))
     if flat is not None:
         cfg["flat"] = flat
     if ids is not None:

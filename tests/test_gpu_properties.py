@@ -259,5 +259,12 @@ def test_live_slab_weight_gradients_equal_the_full_contraction():
         if k == "loss":
             continue
         (s0, a0), (s1, a1) = a[k], b[k]
+        if k.startswith("news_encoder.multi_head_self_attn") and k.endswith("bias"):
+            # NR_NO_SLABS also switches the compact row storage off: db_qkv then comes from the weight-gradient GEMM's column sums
+            # over bf16-rounded rows instead of the attention backward's row / column sums (tests/test_gpu_scale_parity.py);
+            # d W_K.bias is analytically 0 -- rounding noise in the one, ~1e-11 in the other
+            if not k.endswith("W_K.bias"):
+                assert abs(a0 - a1) <= 5e-3 * a0 + 1e-6, (k, a0, a1)
+            continue
         assert abs(a0 - a1) <= 1e-4 * a0 + 1e-6, (k, a0, a1)
         assert abs(s0 - s1) <= 1e-4 * a0 + 1e-6, (k, s0, s1)
