@@ -1469,14 +1469,16 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {   // n is wave-uniform
 // MODE of the weights-in-registers kernel: how a workgroup finds its row blocks
 enum { WREG_DENSE = 0,    // blocks b0 + k * stride of the dense rows
        WREG_COMPACT = 1,  // the same over the compacted live rows (ep.row_count / ep.row_idx); row numbers ride with the stages
-       WREG_LIST = 2 };   // dense rows, but only blocks that touch a sequence flagged in ep.seq_nz (list built in the prologue)
+       WREG_LIST = 2,     // dense rows, but only blocks that touch a sequence flagged in ep.seq_nz (list built in the prologue)
+       WREG_COMPACT_DENSE = 3 };  // COMPACT whose A operand is itself stored in live-list order (A row k = live row k): the row
+                                  // numbers only scatter the output rows
 
 template <int EPI, int TPW, int KS, int RT, int MODE, bool SEQ = false>
 struct WregCfg {
   static constexpr int NW = 8, R = 16 * RT;
   static constexpr int GCOLS = NW * TPW * 16;                         // columns of a group
   static constexpr int APIECES = RT * KS;                             // 1-KB pieces: 16 rows x 64 B per (row tile, k-step)
-  static constexpr int RIDER = MODE == WREG_COMPACT ? 1 : 0;          // row numbers
+  static constexpr int RIDER = (MODE == WREG_COMPACT || MODE == WREG_COMPACT_DENSE) ? 1 : 0;   // row numbers
   static constexpr int GT = 3, GP = (GCOLS * 4 + 1023) / 1024;        // POOLBWD: pooled-gradient rows of up to GT sequences
   static constexpr int PBW = EPI == EPI_POOLBWD ? 1 + GT * GP : 0;    //          alpha of the block's rows + those G rows
   static constexpr int PIECES = APIECES + RIDER + PBW;
@@ -1499,7 +1501,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restr
   using Cfg = WregCfg<EPI, TPW, KS, RT, MODE, SEQ>;
   constexpr int NW = Cfg::NW, R = Cfg::R, NS = Cfg::NS, PW = Cfg::PW, STAGE = Cfg::STAGE, S = Cfg::S, GCOLS = Cfg::GCOLS;
   constexpr int APIECES = Cfg::APIECES, GT = Cfg::GT, GP = Cfg::GP;
-  constexpr bool COMPACT = MODE == WREG_COMPACT, LISTED = MODE == WREG_LIST, PB = EPI == EPI_POOLBWD;
+  constexpr bool ADENSE = MODE == WREG_COMPACT_DENSE, COMPACT = MODE == WREG_COMPACT || ADENSE, LISTED = MODE == WREG_LIST, PB = EPI == EPI_POOLBWD;
   constexpr int P_RIDER = APIECES;                       // piece index of the row-number rider (COMPACT)
   constexpr int P_ALPHA = APIECES + Cfg::RIDER;          // POOLBWD: alpha piece, then GT * GP pieces of G rows
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1611,7 +1613,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restr
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       const int row = blk(kk) * R + 16 * i + prow;
-      arow[i] = (kk >= nsteps || row >= M) ? 0 : ((COMPACT && !ep.a_dense) ? ep.row_idx[row] : row);
+      arow[i] = (kk >= nsteps || row >= M) ? 0 : ((COMPACT && !ADENSE) ? ep.row_idx[row] : row);
     }
   };
 #pragma unroll 1
@@ -1625,60 +1627,20 @@ __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restr
   bf16_t* Cb = (bf16_t*)ep.C;
   uint4* dump_g = g_nt_dump + wid * 64 + lane;
 
-#pragma unroll 1
-  for (int k = 0; k < nsteps; ++k) {
-    if (k >= NS - 1) {                             // steady state: one immediate
-      constexpr int STEADY = (NS - 2) * PW + (NS - 1) * S;
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
-    } else {
-      wait_vmcnt_le((NS - 2) * PW + k * S);
-    }
-    __builtin_amdgcn_s_barrier();                  // stage k is in LDS for everyone; everyone is done with stage k-1
-    const char* st = smem + (k % NS) * STAGE;
-    const int b = blk(k);
-    int ar[RT], mout[RT];
-    {
-      const int bn = blk(k + NS - 1);
-      const int* rid = reinterpret_cast<const int*>(st + P_RIDER * 1024);
-#pragma unroll
-      for (int i = 0; i < RT; ++i) {
-        const int rown = bn * R + 16 * i + prow;
-        const bool ok = k + NS - 1 < nsteps && rown < M;
-        ar[i] = !ok ? 0 : ((COMPACT && !ep.a_dense) ? rid[R + 16 * i + prow] : rown);
-        mout[i] = COMPACT ? rid[16 * i + fr] : b * R + 16 * i + fr;
-      }
-    }
-    issue_stage(k + NS - 1, ar);
+  // Tried and dropped (round 3): running the last pass's epilogue of waves 4..7 after the NEXT barrier (accumulators live across
+  // it, one extra register) so that a SIMD's two waves alternate MFMA and epilogue phases instead of marching in lockstep --
+  // same box A/B at the QKV shape: 0.242 -> 0.280 ms.  The late waves issue their DMAs ~500 cycles after the barrier then.
+  constexpr int RP = SEQ ? 1 : RT, NPASS = RT / RP;     // row tiles per pass through the accumulators
+  f32x4 acc[RP][TPW];
 
-    constexpr int RP = SEQ ? 1 : RT, NPASS = RT / RP;     // row tiles per pass through the accumulators
-#pragma unroll
-    for (int q = 0; q < NPASS; ++q) {
-    f32x4 acc[RP][TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + (wid * TPW + t) * 16 + 4 * g);
-#pragma unroll
-      for (int i = 0; i < RP; ++i) acc[i][t] = bv;
-    }
-    if (wcol0 < Ntot) {                            // wave-uniform: a wave whose tiles are all beyond N only keeps step with the others
-#pragma unroll
-      for (int s2 = 0; s2 < KS; ++s2) {
-#pragma unroll
-        for (int ii = 0; ii < RP; ++ii) {
-          const int i = q * RP + ii;
-          const bf16x8 af = *reinterpret_cast<const bf16x8*>(st + (i * KS + s2) * 1024 + offA);
-#pragma unroll
-          for (int t = 0; t < TPW; ++t) acc[ii][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][s2], af, acc[ii][t], 0, 0, 0);
-        }
-      }
-    }
-    // ---- epilogue: exactly S stores per wave and stage
+  // epilogue of pass q of the stage that block b / output rows mo belong to: exactly S / NPASS stores
+  auto epilogue = [&](int q, int b, const int (&mo)[RT], const char* st) {
 #pragma unroll
     for (int ii = 0; ii < RP; ++ii) {
       const int i = q * RP + ii;
       const int m = b * R + 16 * i + fr;
       const bool rok = m < M;
-      bf16_t* crow = Cb + (size_t)mout[i] * ep.ldc;
+      bf16_t* crow = Cb + (size_t)mo[i] * ep.ldc;
       float al = 0.f;
       const float* grow = nullptr;
       if (PB) {
@@ -1721,6 +1683,55 @@ __global__ __launch_bounds__(512) void gemm_nt_wreg_kernel(const bf16_t* __restr
         }
       }
     }
+  };
+
+#pragma unroll 1
+  for (int k = 0; k < nsteps; ++k) {
+    if (k >= NS - 1) {                             // steady state: one immediate
+      constexpr int STEADY = (NS - 2) * PW + (NS - 1) * S;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STEADY) : "memory");
+    } else {
+      wait_vmcnt_le((NS - 2) * PW + k * S);
+    }
+    __builtin_amdgcn_s_barrier();                  // stage k is in LDS for everyone; everyone is done with stage k-1
+    const char* st = smem + (k % NS) * STAGE;
+    const int b = blk(k);
+    int ar[RT], mout[RT];
+    {
+      const int bn = blk(k + NS - 1);
+      const int* rid = reinterpret_cast<const int*>(st + P_RIDER * 1024);
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        const int rown = bn * R + 16 * i + prow;
+        const bool ok = k + NS - 1 < nsteps && rown < M;
+        ar[i] = !ok ? 0 : ((COMPACT && !ADENSE) ? rid[R + 16 * i + prow] : rown);
+        mout[i] = COMPACT ? rid[16 * i + fr] : b * R + 16 * i + fr;
+      }
+    }
+    issue_stage(k + NS - 1, ar);
+
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + (wid * TPW + t) * 16 + 4 * g);
+#pragma unroll
+        for (int i = 0; i < RP; ++i) acc[i][t] = bv;
+      }
+      if (wcol0 < Ntot) {                          // wave-uniform: a wave whose tiles are all beyond N only keeps step with the others
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) {
+#pragma unroll
+          for (int ii = 0; ii < RP; ++ii) {
+            const int i = q * RP + ii;
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(st + (i * KS + s2) * 1024 + offA);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[ii][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][s2], af, acc[ii][t], 0, 0, 0);
+          }
+        }
+      }
+      // ---- epilogue: exactly S stores per wave and stage
+      epilogue(q, b, mout, st);
     }
   }
 }
@@ -2968,6 +2979,7 @@ int nr_launch_gemm_nt(int dtype, const RowSrc& A, const void* B, int ldb, int M,
                                      : (ep.seq_nz ? "gemm_nt_wreg_needed[bf16,epi=%d,Mmax=%d,N=%d,K=%d]" : "gemm_nt_wreg[bf16,epi=%d,M=%d,N=%d,K=%d]");
       if (epi == EPI_STORE && !tile_skip && K > 288 && K <= 320 && N >= 320) {
         NrProfScope ps(stream, lbl, epi, M, N, K);
+        if (ep.row_count && ep.a_dense) return launch_nt_wreg_m<EPI_STORE, 5, 10, 2, WREG_COMPACT_DENSE, true>(A, B, ldb, M, N, K, ep, stream);
         if (nr_opt(NR_OPT_NT_WREG) == 3)           // 16-row stages (one row tile per barrier)
           return ep.row_count ? launch_nt_wreg_m<EPI_STORE, 5, 10, 1, WREG_COMPACT>(A, B, ldb, M, N, K, ep, stream)
                               : launch_nt_wreg_m<EPI_STORE, 5, 10, 1, WREG_DENSE>(A, B, ldb, M, N, K, ep, stream);
