@@ -171,6 +171,10 @@ typedef struct {
                          reach them); farther ones may stay UNWRITTEN.  For callers whose only consumer of y is
                          nr_additive_pool_fwd / _bwd with the same flags on a shape for which nr_pool_contracts_slabs() says 1
                          (it never reads those rows); 0.3 GB of zero stores per step at the news level otherwise.          */
+  int dy_far_unwritten; /* nr_mhsa_bwd only: nonzero = the dy rows of a sequence whose seq_nz flag is 0 are zeros only within 32 / L + 2
+                         sequences of a flagged one, UNWRITTEN memory farther away (nr_pool_desc.dx_far_unwritten): the backward
+                         then takes dy = 0 for every unflagged sequence without reading it.  Needs seq_nz and a descriptor for
+                         which nr_mhsa_compact_rows() says 1 (refused otherwise).                                            */
 } nr_mhsa_desc;
 
 /* qkv: [n*L, 3N] dtype (saved for backward); y: [n*L, N] dtype.
@@ -178,6 +182,9 @@ typedef struct {
  * Q|K|V on chip; nr_mhsa_fwd_fused(d) returns 1 for such a descriptor, and then qkv may be NULL (inference: the
  * projections are never written to HBM).  On every other path qkv is required.                              */
 int nr_mhsa_fwd_fused(const nr_mhsa_desc* d);
+/* 1 when nr_mhsa_fwd / nr_mhsa_bwd keep x_rows and dqkv in compact row storage for this descriptor (bf16 gather source with
+ * x_rows and row_ws, title-level shapes): only then may dy_far_unwritten be used.                                  */
+int nr_mhsa_compact_rows(const nr_mhsa_desc* d);
 /* Bytes of row_ws that nr_mhsa_fwd / nr_mhsa_bwd use for this descriptor (depends on n and L only). */
 size_t nr_mhsa_workspace_bytes(const nr_mhsa_desc* d);
 int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream);
@@ -259,6 +266,10 @@ typedef struct {
                          out row and alpha as zeros and may leave its e rows unwritten; nr_additive_pool_bwd must be given the same
                          flags: the pooled gradient of such a sequence is zero by contract, its dpre / dx rows are written as zeros
                          and its e rows are never read                                                                       */
+  int dx_far_unwritten; /* nr_additive_pool_bwd: nonzero = the dx rows of a sequence with a zero pooled gradient need to be zeros only
+                         within 32 / L + 2 sequences of one with a gradient; farther ones MAY stay unwritten (0.2 GB of zero stores
+                         per step at the news level).  For a caller that hands dx, together with the flags of nr_pool_seq_flags,
+                         to nr_mhsa_bwd with dy_far_unwritten set -- nothing else may read those rows.                       */
 } nr_pool_desc;
 /* 1 when nr_additive_pool_bwd contracts only the 32-row slabs that touch a sequence with a non-zero pooled gradient for this
  * descriptor (n, L, N, q, dtype are read): it then never reads x rows farther than 32 / L + 2 sequences from such a sequence

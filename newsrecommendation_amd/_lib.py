@@ -30,7 +30,7 @@ class MhsaDesc(C.Structure):
                 ("mask", C.c_void_p), ("w_qkv", C.c_void_p), ("ldw", C.c_int), ("b_qkv", C.c_void_p),
                 ("x_rows", C.c_void_p), ("ld_rows", C.c_int), ("row_ws", C.c_void_p), ("row_ws_bytes", C.c_size_t),
                 ("table_rows", C.c_int), ("proj_table", C.c_void_p), ("seq_needed", C.c_void_p), ("seq_nz", C.c_void_p), ("row_ws_ready", C.c_int), ("bwd_phase", C.c_int),
-                ("y_far_unwritten", C.c_int)]
+                ("y_far_unwritten", C.c_int), ("dy_far_unwritten", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -52,7 +52,7 @@ class CastJob(C.Structure):
 class PoolDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("L", C.c_int), ("N", C.c_int), ("q", C.c_int), ("dtype", C.c_int), ("x", C.c_void_p),
                 ("mask", C.c_void_p), ("w1", C.c_void_p), ("ldw1", C.c_int), ("b1", C.c_void_p), ("w2", C.c_void_p),
-                ("b2", C.c_void_p), ("partial_bytes", C.c_size_t), ("seq_needed", C.c_void_p)]
+                ("b2", C.c_void_p), ("partial_bytes", C.c_size_t), ("seq_needed", C.c_void_p), ("dx_far_unwritten", C.c_int)]
 
 
 class LinearDesc(C.Structure):
@@ -94,6 +94,7 @@ SIGNATURES = {
     "nr_embed_gather_bwd": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp],
     "nr_gather_cast_fwd": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _vp],
     "nr_mhsa_fwd_fused": [C.POINTER(MhsaDesc)],
+    "nr_mhsa_compact_rows": [C.POINTER(MhsaDesc)],
     "nr_mhsa_fwd": [C.POINTER(MhsaDesc), _vp, _vp, _vp],
     "nr_mhsa_bwd": [C.POINTER(MhsaDesc), _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "nr_conv1d_k3_fwd": [C.POINTER(ConvDesc), _vp, _vp],

@@ -16,7 +16,7 @@ bool nr_attn_rowsub_ok(int dtype, int L, int d_head, int heads);
 bool nr_attn_compact_ok(int dtype, int L, int d_head, int heads);
 int nr_launch_attn_bwd_compact(const void* qkv, const float* mask, const void* dy, void* dqkv, int n, int L, int heads, int d_head,
                                const DropCfg& drop, hipStream_t stream, const uint32_t* tmask, const float* bias, const int32_t* seq_list,
-                               const int32_t* seq_count, const int32_t* pos, void* dump, float* db);
+                               const int32_t* seq_count, const int32_t* pos, void* dump, float* db, const int32_t* nzf);
 int nr_launch_attn_gather_fwd(const void* proj_table, const int32_t* ids, const float* mask, void* y, int n, int L, int heads,
                               int d_head, const DropCfg& drop, hipStream_t stream);
 int nr_launch_pool_core_fwd(int dtype, const void* x, const void* e, const float* w2, const float* b2, const float* mask,
@@ -26,6 +26,7 @@ int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float
                             int ld_g, void* dpre, float* partial, float* dw2, float* db2, int n, int L, int N, int q,
                             hipStream_t s, const int32_t* seq_nz = nullptr);
 int nr_launch_cast_rows(int dtype, const float* src, int ld_src, void* dst, int ld_dst, int rows, int cols, hipStream_t s);
+int nr_launch_colsum_split(const float* in, int rows, int cols, int ld, float* out, int split, float* out2, hipStream_t s);
 int nr_pool_partial_rows(int n);
 bool nr_mhsa_fused_shape_ok(int L, int heads, int d_head, int d_model, int ldt, int ldw);
 int nr_launch_mhsa_fused_fwd(const void* table, int ldt, const int32_t* ids, const void* w, int ldw, const float* bias,
@@ -46,7 +47,7 @@ struct OptDef { const char* name; int def; };
 const OptDef g_opt_defs[NR_OPT_COUNT] = {
     {"NO_SLABS", 0},   {"NO_ATTN_SKIP", 0}, {"SIDE_STREAM", 0}, {"ATTN_OLD", 0},  {"ATTN_VALU", 0},   {"NO_PAD_SUB", 0},
     {"NO_FUSED_FWD", 0}, {"NO_TN3", 0},     {"TN_V1", 0},       {"TN3_ROUNDS", 0}, {"TN3_WK", 0},      {"TN3_NI", 0},
-    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}, {"NO_ROW_SUB", 0}, {"ATTN_BWD_OCC4", 0}, {"NT_ABLATE", 0}, {"NT_WREG", 1}, {"NO_SCATTER_SORT", 0}, {"TN3_MIN_M", 16384}, {"NO_COMPACT_ROWS", 0}, {"NO_POOL_FUSED", 0}, {"POOL_ABLATE", 0}};
+    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}, {"NO_ROW_SUB", 0}, {"ATTN_BWD_OCC4", 0}, {"NT_ABLATE", 0}, {"NT_WREG", 1}, {"NO_SCATTER_SORT", 0}, {"TN3_MIN_M", 16384}, {"NO_COMPACT_ROWS", 0}, {"NO_POOL_FUSED", 0}, {"ATTN_BWD_GRID", 0}, {"POOL_ABLATE", 0}};
 std::atomic<int> g_opt[NR_OPT_COUNT];
 std::once_flag g_opt_once;
 void opt_init() {
@@ -567,6 +568,8 @@ int nr_mhsa_fwd_fused(const nr_mhsa_desc* d) {
              : 0;
 }
 
+int nr_mhsa_compact_rows(const nr_mhsa_desc* d) { return (d != nullptr && mhsa_check(d) == NR_OK && d->n > 0 && mhsa_compact_rows(d)) ? 1 : 0; }
+
 int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   int rc = mhsa_check(d);
   if (rc) return rc;
@@ -686,6 +689,7 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
     // in the same order; dW = dqkv_c^T . x_c over `count` dense rows, db from the attention kernel, the table gradient reads
     // dqkv_c through the id-sorted positions
     NR_CHECK_ARG(tmask != nullptr, "mhsa_bwd: the forward stored x_rows compactly; qkv / dy / dqkv must be 8-byte aligned");
+    NR_CHECK_ARG(!d->dy_far_unwritten || d->seq_nz != nullptr, "mhsa_bwd: dy_far_unwritten needs the seq_nz flags");
     NR_CHECK_ARG(dtable != nullptr && dx == nullptr && w_qkv_t != nullptr && ldwt >= 3 * N, "mhsa_bwd: gather source takes dtable (and w_qkv_t [d_model, >=3N])");
     int32_t* ws = d->row_ws;
     if (ph_main) {
@@ -702,7 +706,7 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
       // rows count .. roundup32(count) of dqkv: the weight-gradient GEMM contracts whole 32-row slabs (x_c is zero there)
       if ((rc = nr_launch_zero_tail_rows(dqkv, 3 * N, ws, M, s))) return rc;
       if ((rc = nr_launch_attn_bwd_compact(qkv, d->mask, dy, dqkv, d->n, d->L, d->heads, d->d_head, nr_make_drop(d->p_out, d->seed_out), s, tmask,
-                                           d->b_qkv, seq_ws + 4, seq_ws, ws + W.pos, ws + W.dump, db_qkv)))
+                                           d->b_qkv, seq_ws + 4, seq_ws, ws + W.pos, ws + W.dump, db_qkv, d->dy_far_unwritten ? slab_ws : nullptr)))
         return rc;
       // table gradient: rows in token-id order, A rows through their live-list positions
       if ((rc = nr_launch_sort_rows_by_id(ws, ws + W.live_idx, ws + W.live_ids, M, d->table_rows, ws + W.hist, ws + W.sort_idx, ws + W.sort_ids, s,
@@ -718,6 +722,7 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
       return rc;
     return NR_OK;
   }
+  NR_CHECK_ARG(!d->dy_far_unwritten, "mhsa_bwd: dy_far_unwritten is only honoured with compact row storage (nr_mhsa_compact_rows)");
   // Sequences whose upstream gradient dy is exactly zero (history slots the user encoder masks out) get exact zeros in
   // dQ|dK|dV (dP = dy.V^T = 0, so dS = 0): a pass over dy flags the others, and the weight-gradient GEMM contracts only
   // the 32-row slabs that touch a flagged sequence.  Scratch: the tail of row_ws (n flags, count, M/32 slab ids).
@@ -974,6 +979,18 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
   // Without the flags derived from g (small / fp32 shapes) the caller's "output not needed" flags serve: such a sequence has a
   // zero pooled gradient by contract, and its e rows may never have been written by the forward.
   const int32_t* zero_flags = ws != nullptr ? ws : d->seq_needed;
+  // title-level shapes with slab flags and an input gradient asked for: dA, ds, dpre, dX and the dw2 / db2 partial sums in ONE
+  // kernel (x and e read once, dpre never read back for dX); the weight gradient dW1 = dpre^T . x below is unchanged
+  if (ws != nullptr && dx != nullptr && w1_t != nullptr && nr_pool_fused_bwd_ok(d->dtype, d->n, d->L, d->N, d->q, ldw1t) && ld_g % 4 == 0 &&
+      ((((uintptr_t)d->x) | ((uintptr_t)e) | ((uintptr_t)w1_t) | ((uintptr_t)dpre) | ((uintptr_t)dx) | ((uintptr_t)g)) & 15) == 0 && d->N % 8 == 0) {
+    int rows = 0;
+    if ((rc = nr_launch_pool_fused_bwd(d->x, d->N, e, d->q, alpha, g, ld_g, d->w2, w1_t, ldw1t, dpre, d->q, dx, d->N, partial,
+                                       nr_pool_partial_rows(d->n), ws, d->n, d->L, d->N, d->q, s, &rows, d->dx_far_unwritten)))
+      return rc;
+    if ((rc = nr_launch_colsum_split(partial, rows, d->q + 1, d->q + 1, dw2, d->q, db2, s))) return rc;
+    if ((rc = nr_launch_live_slabs(ws, d->n, d->L, s))) return rc;
+    return nr_launch_gemm_tn_slabs(dpre, d->q, d->x, d->N, dw1, d->N, db1, M, d->q, d->N, d->q, d->N, ws + d->n + 4, ws + d->n, s);
+  }
   if ((rc = nr_launch_pool_core_bwd(d->dtype, d->x, e, d->w2, alpha, g, ld_g, dpre, partial, dw2, db2, d->n, d->L, d->N, d->q, s, zero_flags)))
     return rc;
   RowSrc X = dense_rows(d->x, d->N, d->N);

@@ -50,6 +50,8 @@ struct AttnMArgs {
   void* dump;             // 3N elements of scratch: where the (unpredicated) stores of an all-padding sequence land
   float* db;              // [3N] fp32, ACCUMULATED: column sums of dQ | dK | dV over every row of every sequence walked -- the bias
                           //   gradient, produced here because the padding rows that carry part of it are no longer stored
+  const int32_t* nzf;     // optional [n]: 0 = this sequence's dy is zero BY CONTRACT and its rows may be unwritten memory: the kernel
+                          //   puts zeros into the G image instead of what it loaded (nr_mhsa_desc.dy_far_unwritten)
 };
 
 __device__ __forceinline__ int rowof(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -980,6 +982,7 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
   if (CPT)
     for (int i = tid; i < hgroups * AW * 96; i += AW * 64) sDb[i] = 0.f;
   int pos_next = 0;                                      // CPT: dqkv row of token (tid & 31) of the prefetched sequence
+  bool gz_seq = false;                                   // CPT: the prefetcher's sequence has dy = 0 by contract (a.nzf): its rows are not trusted
   uint32_t tm_cur = 0;                                   // CPT: live-token mask of the CURRENT item's sequence
   ItemIter it{(int)blockIdx.x, 0}, nx{(int)blockIdx.x, 0};
   Panel<PT> rq, rk, rv, rg;
@@ -1001,6 +1004,7 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
           tm_seq = sload_u32(a.tmask + sq_next);
           dead_seq = tm_seq == 0;
         }
+        if (CPT) gz_seq = a.nzf != nullptr && sload_u32(a.nzf + sq_next) == 0;
       }
     } else {
       sq_next = listed ? a.seq_list[t.sb] : t.sb;
@@ -1054,7 +1058,12 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
       panel_put<false, PT, FULL>(rk, imK, pc, nodrop, 0, 0);
       panel_put<false, PT, FULL>(rv, imV, pc, nodrop, 0, 0);
     }
-    panel_put<true, PT, FULL>(rg, imG, pc, a.drop, (uint32_t)(r0 * N) + (uint32_t)(t.hg * AW * d), N);
+    if (CPT && gz_seq) {                                 // (workgroup-uniform) dy = 0 by contract: what was loaded may be anything
+#pragma unroll
+      for (int t2 = 0; t2 < PT; ++t2) *reinterpret_cast<bf16x4*>(imG + pc.loff(t2)) = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+    } else {
+      panel_put<true, PT, FULL>(rg, imG, pc, a.drop, (uint32_t)(r0 * N) + (uint32_t)(t.hg * AW * d), N);
+    }
     if (HAS_MASK && lane < 32) sMask[lane] = (lane < L && t.hg * AW + wid < heads) ? a.mask[r0 + lane] : 0.f;
     if (CPT) {
       if (tid < 32) sPos[tid] = pos_next;
@@ -1746,6 +1755,7 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   const int hgroups = (a.heads + AW - 1) / AW;
   const size_t smem_s = smem + (sub ? (size_t)((3 * a.N + 7) / 8) * 8 * sizeof(bf16_t) : 0) +
                         (cpt ? (size_t)(32 + AW * 96 + hgroups * AW * 96) * sizeof(float) : 0);
+  if (cpt && nr_opt(NR_OPT_ATTN_BWD_GRID) > 0) blocks = std::min<long>(blocks, nr_opt(NR_OPT_ATTN_BWD_GRID));
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(AW * 64), smem_s, stream, a); };
   // FULL: all head slots real and the store panels alias the images (d <= 21 in the backward): unpredicated memory
   // instructions, counted waits (see fwd_kernel)
@@ -1825,7 +1835,7 @@ int nr_launch_attn_mfma(bool bwd, int dtype, const void* qkv, const float* mask,
   if (!nr_attn_mfma_supported(L, d_head)) return -1;
   AttnMArgs a;
   a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr; a.ids = nullptr; a.needed = needed;
-  a.pos = nullptr; a.dump = nullptr; a.db = nullptr;
+  a.pos = nullptr; a.dump = nullptr; a.db = nullptr; a.nzf = nullptr;
   a.qkv = qkv; a.mask = mask; a.y = y; a.dy = dy; a.dqkv = dqkv;
   a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;
   a.scale = 1.0f / sqrtf((float)d_head);
@@ -1858,7 +1868,7 @@ bool nr_attn_compact_ok(int dtype, int L, int d_head, int heads) { return nr_att
 
 int nr_launch_attn_bwd_compact(const void* qkv, const float* mask, const void* dy, void* dqkv, int n, int L, int heads, int d_head,
                                const DropCfg& drop, hipStream_t stream, const uint32_t* tmask, const float* bias, const int32_t* seq_list,
-                               const int32_t* seq_count, const int32_t* pos, void* dump, float* db) {
+                               const int32_t* seq_count, const int32_t* pos, void* dump, float* db, const int32_t* nzf) {
   NR_CHECK_ARG(nr_attn_compact_ok(NR_BF16, L, d_head, heads) && tmask && bias && pos && dump && db && qkv && dy && dqkv,
                "attention backward (compact rows): shape or operands not eligible");
   NR_CHECK_ARG(((((uintptr_t)qkv) | ((uintptr_t)dy) | ((uintptr_t)dqkv) | ((uintptr_t)dump)) & 7) == 0, "attention backward (compact rows): 8-byte alignment");
@@ -1870,7 +1880,7 @@ int nr_launch_attn_bwd_compact(const void* qkv, const float* mask, const void* d
   a.drop = drop;
   a.vec = 1;
   a.tmask = tmask; a.bias = bias; a.seq_list = seq_list; a.seq_count = seq_list ? seq_count : nullptr;
-  a.pos = pos; a.dump = dump; a.db = db;
+  a.pos = pos; a.dump = dump; a.db = db; a.nzf = nzf;
   NrProfScope ps(stream, "attn_mfma_bwd_rows[bf16,n=%d,L=%d,h=%d,d=%d]", n, L, heads, d_head);
   return b16::launch(true, a, stream);
 }
@@ -1890,7 +1900,7 @@ int nr_launch_attn_gather_fwd(const void* proj_table, const int32_t* ids, const 
   if ((!nr_attn_pad_ok(NR_BF16, L, d_head, proj_table, y) && !long_seq) || ids == nullptr) return -1;
   AttnMArgs a;
   a.tmask = nullptr; a.bias = nullptr; a.seq_list = nullptr; a.seq_count = nullptr; a.needed = nullptr;
-  a.pos = nullptr; a.dump = nullptr; a.db = nullptr;
+  a.pos = nullptr; a.dump = nullptr; a.db = nullptr; a.nzf = nullptr;
   a.ids = ids;
   a.qkv = proj_table; a.mask = mask; a.y = y; a.dy = nullptr; a.dqkv = nullptr;
   a.n = n; a.L = L; a.heads = heads; a.d = d_head; a.N = heads * d_head;

@@ -103,6 +103,11 @@ int nr_launch_pool_fused_fwd(const void* x, int ldx, const void* w1, int ldw1, c
                              const int32_t* needed, hipStream_t stream);
 int nr_launch_gemm_tn_counted(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, int Mmax, int N, int K, int Nstore,
                               int Kstore, const int32_t* row_count, hipStream_t stream);
+// fused additive-pooling backward core (dA, ds, dpre, dX, dw2 / db2 partials); see pool_fused_bwd_kernel
+int nr_pool_fused_bwd_ok(int dtype, int n, int L, int N, int q, int ldw1t);
+int nr_launch_pool_fused_bwd(const void* x, int ldx, const void* e, int lde, const float* alpha, const float* g, int ldg, const float* w2,
+                             const void* w1t, int ldw1t, void* dpre, int ldp, void* dx, int lddx, float* partial, int partial_rows,
+                             const int32_t* nz, int n, int L, int N, int q, hipStream_t stream, int* grid_out, int dx_far_unwritten = 0);
 // live rows only, in live-list order (count / rows / ids of nr_launch_compact_rows_fwd), zero-filled to a multiple of 32 rows
 int nr_launch_gather_live_rows(int dtype, const RowSrc& A, void* out, int ldo, int Mmax, int K, const int32_t* count, const int32_t* rows,
                                const int32_t* ids, hipStream_t stream);

@@ -2068,6 +2068,369 @@ __global__ __launch_bounds__(512) void pool_fused_fwd_kernel(PoolFusedArgs a, in
   }
 }
 
+// =========================================================================================
+// Fused additive-attention pooling BACKWARD core for sequences of L <= 32 tokens (src/model/model_utils.py:21-30 differentiated):
+//   dA_l = <g, x_l> ; ds_l = a_l (dA_l - sum_u a_u dA_u) ; dpre_l = ds_l w2 (1 - e_l^2) ; dX_l = dpre_l W1 + a_l g
+//   dw2 += sum_l ds_l e_l ; db2 += sum_l ds_l                       (dW1 = dpre^T x stays with the weight-gradient GEMM)
+// The unfused path ran pool_core_bwd (x, e in; dpre out) and the weights-in-registers dX GEMM (dpre in again; dX out): 0.25 +
+// 0.19 ms at the news level.  Here a stage = ONE SEQUENCE, three sequences are in flight, one barrier per step k:
+//   S0  DMA e | g of sequence k + 2 into the ring (the e pieces in the MFMA fragment layout)
+//   A   sequence k    : dA partials -- this wave's k-steps of x . g on the matrix cores (g as bf16 hi + lo; the x fragments
+//       come straight from global memory into registers, loaded one step ahead: x never goes through LDS)      -> sPartA
+//   B   sequence k - 1: dA, ds (every wave, 32 lanes); the workgroup's 8-column chunks of dpre = ds w2 (1 - e^2) written
+//       IN PLACE over e in the ring and to global memory; dw2 / db2 partial sums in registers
+//   C   sequence k - 2: dX = dpre . W1 (W1^T resident in registers, A fragments from the ring) + alpha g    -> global (bf16)
+// Sequences with a zero pooled gradient (flags) are left out of the walk: their dX rows are zero-filled in the prologue, their
+// dpre rows only where a 32-row slab of the weight-gradient GEMM can reach them (within `reach` sequences of a live one).
+// Vector-memory bookkeeping is static: every wave issues PW DMAs, 5 loads and 6 stores per step, in that order.
+// =========================================================================================
+struct PoolFusedBwdArgs {
+  const bf16_t* x; int ldx;          // [n * L, ldx]
+  const bf16_t* e; int lde;          // [n * L, lde]
+  const float* alpha;                // [n * L]
+  const float* g; int ldg;           // [n, ldg] pooled gradient
+  const float* w2;                   // [q]
+  const bf16_t* w1t; int ldw1t;      // [N, ldw1t] = W1^T packed (zero beyond q up to a multiple of 32)
+  bf16_t* dpre; int ldp;             // [n * L, ldp] out
+  bf16_t* dx; int lddx;              // [n * L, lddx] out
+  float* partial;                    // [gridDim.x, q + 1] out: this workgroup's dw2 | db2
+  const int32_t* nz;                 // [n] or null: 0 = zero pooled gradient
+  int n, L, N, q;
+  int dx_far_unwritten;              // dX rows of zero-gradient sequences far from every live one stay unwritten (nr_pool_desc)
+};
+
+template <int KS, int KS2>
+struct PoolFusedBwdCfg {
+  static constexpr int NW = 8, TPW = 4, RT = 2, R = 32;
+  static constexpr int EPIECES = RT * KS2, GPIECES = 2, PIECES = EPIECES + GPIECES;
+  static constexpr int PW = (PIECES + NW - 1) / NW, STAGE = PIECES * 1024, NS = 5;
+  static constexpr int LOADS = 5;                                       // 2 row tiles x 2 k-steps of x + alpha
+  static constexpr int OPS = PW + LOADS + 2 + RT * 2;                   // + dpre stores + dX stores
+  static constexpr int STEADY = 2 * OPS - PW;                           // ops younger than stage k's DMAs at the top of step k
+  static constexpr int DUMP = NS * STAGE;                               // per-wave dump piece
+  static constexpr int PARTA = DUMP + NW * 1024;                        // sPartA [2][NW][32] fp32
+  static constexpr int ALPHA = PARTA + 2 * NW * 32 * 4;                 // sAlpha [4][32] fp32
+  static constexpr int W2 = ALPHA + 4 * 32 * 4;                         // sW2 [256] fp32 | sRedW [256] fp32
+  static constexpr int ACCW = W2 + 2 * 256 * 4;                         // per-thread dw2 partial sums [512][16] fp32 (registers are full)
+  static constexpr int LIST = ACCW + 512 * 16 * 4;
+  static_assert(STEADY <= 62, "vmcnt is a 6-bit counter");
+};
+
+template <int KS, int KS2>
+__global__ __launch_bounds__(512) void pool_fused_bwd_kernel(PoolFusedBwdArgs a, int reach) {
+  using Cfg = PoolFusedBwdCfg<KS, KS2>;
+  constexpr int NW = Cfg::NW, TPW = Cfg::TPW, RT = Cfg::RT, NS = Cfg::NS, PW = Cfg::PW, STAGE = Cfg::STAGE, EPIECES = Cfg::EPIECES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, g = lane >> 4;
+  const int prow = lane >> 2, c8 = ((lane & 3) ^ swzP(prow)) * 8;
+  const int L = a.L, N = a.N, q = a.q, M = a.n * a.L, qc = q >> 3;
+  float* sPartA = reinterpret_cast<float*>(smem + Cfg::PARTA);
+  float* sAlpha = reinterpret_cast<float*>(smem + Cfg::ALPHA);
+  float* sW2 = reinterpret_cast<float*>(smem + Cfg::W2);
+  float* sRedW = sW2 + 256;
+  int* sList = reinterpret_cast<int*>(smem + Cfg::LIST);
+
+  // ---- the walk: this workgroup's sequences with a non-zero pooled gradient; zeros for the others
+  const int G = gridDim.x, b0 = blockIdx.x;
+  int nsteps = b0 < a.n ? (a.n - b0 + G - 1) / G : 0;
+  if (a.nz != nullptr) {
+    __shared__ int sCnt[NW + 1];
+    const int cand = nsteps;
+    int run = 0;
+    for (int base = 0; base < cand; base += 512) {
+      const int c = base + tid, sq = b0 + c * G;
+      const bool live = c < cand && a.nz[sq] != 0;
+      const uint64_t bal = __ballot(live);
+      if (lane == 0) sCnt[wid] = __popcll(bal);
+      __syncthreads();
+      int before = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const int cw = sCnt[w];
+        before += w < wid ? cw : 0;
+        total += cw;
+      }
+      if (live) sList[run + before + __popcll(bal & ((1ull << lane) - 1ull))] = sq;
+      run += total;
+      __syncthreads();
+    }
+    for (int c = wid; c < cand; c += NW) {                 // a wave per zero-gradient sequence
+      const int sq = b0 + c * G;
+      if (a.nz[sq] != 0) continue;                         // wave-uniform
+      bool near = false;
+      for (int t = max(0, sq - reach) + lane; t <= min(a.n - 1, sq + reach); t += 64) near |= a.nz[t] != 0;
+      near = __ballot(near) != 0ull;
+      const size_t r0 = (size_t)sq * L;
+      const int xc = N >> 3;
+      if (near || !a.dx_far_unwritten)
+        for (int u = lane; u < L * xc; u += 64) {
+          const int row = u / xc, ch = u - row * xc;
+          *reinterpret_cast<uint4*>(a.dx + (r0 + row) * a.lddx + ch * 8) = make_uint4(0, 0, 0, 0);
+        }
+      if (near)
+        for (int u = lane; u < L * qc; u += 64) {
+          const int row = u / qc, ch = u - row * qc;
+          *reinterpret_cast<uint4*>(a.dpre + (r0 + row) * a.ldp + ch * 8) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    nsteps = run;
+  } else {
+    for (int c = tid; c < nsteps; c += 512) sList[c] = b0 + c * G;
+  }
+  for (int c = tid; c < 256; c += 512) {
+    sW2[c] = c < q ? a.w2[c] : 0.f;
+    sRedW[c] = 0.f;
+  }
+  // ---- W1^T slice of this wave: TPW column tiles x KS2 k-steps
+  const int wcol0 = wid * TPW * 16;
+  bf16x8 bfr[TPW][KS2];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const bf16_t* brow = a.w1t + (size_t)min(wcol0 + t * 16 + fr, N - 1) * a.ldw1t + 8 * g;
+#pragma unroll
+    for (int s2 = 0; s2 < KS2; ++s2) bfr[t][s2] = *reinterpret_cast<const bf16x8*>(brow + 32 * s2);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): nothing of the prologue is carried into the loop
+  __syncthreads();
+  float* prow_out = a.partial + (size_t)blockIdx.x * (q + 1);
+  if (nsteps == 0) {                                       // (the caller sums every workgroup's partial row)
+    for (int c = tid; c <= q; c += 512) prow_out[c] = 0.f;
+    return;
+  }
+
+  const uint32_t dump_lds = lds0 + Cfg::DUMP + wid * 1024;
+  uint4* dump_g = g_nt_dump + wid * 64 + lane;
+  auto issue_stage = [&](int kk) {
+    const uint32_t slot = lds0 + (kk % NS) * STAGE;
+    const bool real = kk < nsteps;
+    const int sq = real ? sList[kk] : 0;
+    const int row0 = sq * L;
+#pragma unroll
+    for (int u = 0; u < PW; ++u) {
+      const int p = wid + NW * u;                          // wave-uniform
+      if (real && p < EPIECES) {
+        const int i = p / KS2, s2 = p - i * KS2;
+        const bf16_t* rp = a.e + (size_t)min(row0 + 16 * i + prow, M - 1) * a.lde + c8;
+        dma16(rp + min(32 * s2, q - 8 - c8), slot + p * 1024);       // (K tail: a valid chunk again; W1^T is zero there)
+      } else if (real && p < EPIECES + Cfg::GPIECES) {
+        const int j = p - EPIECES;
+        dma16(a.g + (size_t)sq * a.ldg + min(256 * j + 4 * lane, N - 4), slot + p * 1024);
+      } else {
+        dma16(a.e + c8, dump_lds);
+      }
+    }
+  };
+  // x fragments of this wave for phase A: k-steps wid and wid + 8 (the second one empty for waves 5..7), both row tiles;
+  // alpha of the same sequence (lane = row), for its phase B one step later
+  const int ks0 = wid, ks1 = wid + NW;
+  // (step k loads the x fragments of sequence k + 1 -- its phase A runs at step k + 1 -- and the alpha of sequence k, whose
+  //  phase B runs at step k + 1 too)
+  auto load_seq = [&](int kk, bf16x8 (&xf)[RT][2], float& al) {
+    const int row0 = sList[kk < nsteps ? kk : 0] * L;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      const bf16_t* rp = a.x + (size_t)min(row0 + 16 * i + fr, M - 1) * a.ldx;
+      xf[i][0] = *reinterpret_cast<const bf16x8*>(rp + min(32 * ks0 + 8 * g, N - 8));
+      xf[i][1] = *reinterpret_cast<const bf16x8*>(rp + min(32 * ks1 + 8 * g, N - 8));
+    }
+    const int rowa = sList[(kk >= 1 && kk - 1 < nsteps) ? kk - 1 : 0] * L;
+    al = a.alpha[min(rowa + (lane & 31), M - 1)];
+  };
+  // g as the MFMA A operand of k-step ks: elements 32 ks + 8 g .. + 7 of the pooled-gradient row, split bf16 hi + lo
+  auto g_frag = [&](const float* grow, int ks, bf16x8& hi, bf16x8& lo) {
+    const int k0 = 32 * ks + 8 * g;
+    const bool ok = ks < KS && k0 < N;                      // (the clamped x chunks beyond N meet zeros here)
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(grow + min(k0, N - 8));
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(grow + min(k0, N - 8) + 4);
+#pragma unroll
+    for (int e2 = 0; e2 < 8; ++e2) {
+      const float v = ok ? (e2 < 4 ? v0[e2] : v1[e2 - 4]) : 0.f;
+      const bf16_t h = (bf16_t)v;
+      hi[e2] = h;
+      lo[e2] = (bf16_t)(v - (float)h);
+    }
+  };
+  auto sum32 = [&](float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v + __shfl_xor(v, 16, 64);
+  };
+  const int offA = fr * 64 + ((g ^ swzP(fr)) << 4);
+  const uint32_t inv_qc = (uint32_t)((0x100000000ull + (uint32_t)qc - 1) / (uint32_t)qc);
+  // phase B geometry: this thread's two 8-column chunks (the same columns every step)
+  int brow[2], bcc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const uint32_t u = (uint32_t)(tid + 512 * j);
+    uint32_t r = __umulhi(u, inv_qc);
+    if (r * (uint32_t)qc > u) --r;
+    brow[j] = (int)r;
+    bcc[j] = (int)(u - r * (uint32_t)qc);
+  }
+
+  bf16x8 xf[RT][2];
+  float al_nb, al_cur = 0.f;
+  // dw2 partial sums of this thread's two chunks: a private strip of LDS, [j][thread] x 8 floats (conflict-free b128 accesses)
+  float* myacc = reinterpret_cast<float*>(smem + Cfg::ACCW) + tid * 8;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    *reinterpret_cast<f32x4*>(myacc + j * 4096) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(myacc + j * 4096 + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float accb = 0.f;
+
+#pragma unroll 1
+  for (int kk = 0; kk < 2; ++kk) issue_stage(kk);
+  load_seq(0, xf, al_nb);
+
+#pragma unroll 1
+  for (int k = 0; k < nsteps + 2; ++k) {
+    // stage k landed: younger than its DMAs are all ops of step k-1 and those of step k-2 behind its DMA issue
+    if (k >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::STEADY) : "memory");
+    else wait_vmcnt_le(k == 0 ? PW + Cfg::LOADS : Cfg::OPS + Cfg::LOADS);
+    __builtin_amdgcn_s_barrier();
+    issue_stage(k + 2);                                                       // S0
+    // ---- A: sequence k -> partial dA from the x fragments loaded one step ago; then fetch those of sequence k + 1
+    auto phase_a = [&]()     {
+      const bool real = k < nsteps;
+      const float* grow = reinterpret_cast<const float*>(smem + (k % NS) * STAGE + EPIECES * 1024);
+      f32x4 da[RT];
+#pragma unroll
+      for (int i = 0; i < RT; ++i) da[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (real) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf16x8 hi, lo;
+          g_frag(grow, j == 0 ? ks0 : ks1, hi, lo);
+#pragma unroll
+          for (int i = 0; i < RT; ++i) {
+            da[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hi, xf[i][j], da[i], 0, 0, 0);
+            da[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lo, xf[i][j], da[i], 0, 0, 0);
+          }
+        }
+      }
+      if (g == 0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) sPartA[((k & 1) * NW + wid) * 32 + 16 * i + fr] = da[i][0];
+      }
+      al_cur = al_nb;                                      // alpha of sequence k - 1 (loaded one step ago) for phase B below
+      load_seq(k + 1, xf, al_nb);
+    };
+    // ---- B: sequence k - 1 -> ds, dpre (in place over e, and to global), dw2 / db2 partial sums
+    auto phase_b = [&]()     {
+      const int kp = k - 1;
+      const bool real = kp >= 0 && kp < nsteps;
+      const int row0 = real ? sList[kp] * L : 0;
+      const bool in = (lane & 31) < L;
+      const float alv = in ? al_cur : 0.f;
+      const float* part = sPartA + ((kp & 1) * NW) * 32 + (lane & 31);
+      float dA = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) dA += part[w * 32];
+      dA = in ? dA : 0.f;                                  // (rows L .. 31 belong to the next sequence: whatever came out of them)
+      const float tsum = sum32(alv * dA);
+      const float ds = alv * (dA - tsum);
+      if (wid == 0 && lane < 32) sAlpha[(kp & 3) * 32 + lane] = alv;
+      if (real) accb += sum32(ds);
+      char* st = smem + ((kp + NS) % NS) * STAGE;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = brow[j], cc = bcc[j];
+        const bool valid = real && row < L;
+        const int rc = min(row, L - 1);
+        const float dsr = __shfl(ds, rc, 64);
+        const int eoff = ((rc >> 4) * KS2 + (cc >> 2)) * 1024 + (rc & 15) * 64 + (((cc & 3) ^ swzP(rc & 15)) << 4);
+        const bf16x8 ev = *reinterpret_cast<const bf16x8*>(st + eoff);
+        const f32x4 wa = *reinterpret_cast<const f32x4*>(sW2 + cc * 8), wb = *reinterpret_cast<const f32x4*>(sW2 + cc * 8 + 4);
+        bf16x8 o;
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(myacc + j * 4096), a1 = *reinterpret_cast<const f32x4*>(myacc + j * 4096 + 4);
+#pragma unroll
+        for (int e2 = 0; e2 < 8; ++e2) {
+          const float f = (float)ev[e2], wv = e2 < 4 ? wa[e2] : wb[e2 - 4];
+          o[e2] = (bf16_t)(dsr * wv * (1.f - f * f));
+          const float p = valid ? dsr * f : 0.f;             // (a step without a sequence reads whatever the ring slot holds)
+          if (e2 < 4) a0[e2] += p;
+          else a1[e2 - 4] += p;
+        }
+        *reinterpret_cast<f32x4*>(myacc + j * 4096) = a0;
+        *reinterpret_cast<f32x4*>(myacc + j * 4096 + 4) = a1;
+        if (valid) *reinterpret_cast<bf16x8*>(st + eoff) = o;
+        uint4* dst = valid ? reinterpret_cast<uint4*>(a.dpre + (size_t)(row0 + row) * a.ldp + cc * 8) : dump_g;
+        *dst = __builtin_bit_cast(uint4, o);
+      }
+    };
+    // ---- C: sequence k - 2 -> dX
+    auto phase_c = [&]()     {
+      const int kc = k - 2;
+      const bool real = kc >= 0 && kc < nsteps;
+      const int row0 = real ? sList[kc] * L : 0;
+      const char* st = smem + ((kc + NS) % NS) * STAGE;
+      const float* grow = reinterpret_cast<const float*>(st + EPIECES * 1024);
+      // the two row tiles one after the other through ONE set of accumulators (16 registers less: the kernel sits at 256)
+#pragma unroll
+      for (int i = 0; i < RT; ++i) {
+        f32x4 acc[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (real && wcol0 < N) {                           // wave-uniform
+#pragma unroll
+          for (int s2 = 0; s2 < KS2; ++s2) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(st + (i * KS2 + s2) * 1024 + offA);
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[t][s2], af, acc[t], 0, 0, 0);
+          }
+        }
+        const int ml = 16 * i + fr;
+        const bool rok = real && ml < L;
+        const float al = sAlpha[((kc + 4) & 3) * 32 + ml];
+        bf16_t* crow = a.dx + (size_t)(row0 + ml) * a.lddx;
+#pragma unroll
+        for (int t = 0; t < TPW; t += 2) {
+          uint2 pk[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int lc = wcol0 + (t + h) * 16 + 4 * g;     // this lane's first column of tile t + h
+            const f32x4 gq = *reinterpret_cast<const f32x4*>(grow + lc);
+            const f32x4 v = acc[t + h];
+            const bf16x4 o = {(bf16_t)(v[0] + al * gq[0]), (bf16_t)(v[1] + al * gq[1]), (bf16_t)(v[2] + al * gq[2]), (bf16_t)(v[3] + al * gq[3])};
+            pk[h] = __builtin_bit_cast(uint2, o);
+          }
+          const auto s0 = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+          const int col = wcol0 + (t + (g & 1)) * 16 + (g >> 1) * 8;
+          uint4* dst = (rok && col + 8 <= N) ? reinterpret_cast<uint4*>(crow + col) : dump_g;
+          *dst = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+      }
+    };
+    // The three phases touch three different sequences and disjoint buffers: any order is legal, and the static vmcnt
+    // bookkeeping only counts operations per step.  The two waves of a SIMD (w and w + 4) take opposite orders, so one runs the
+    // dX MFMAs while the other is in the VALU / LDS phases.
+    if (wid < NW / 2) {
+      phase_a();
+      phase_b();
+      phase_c();
+    } else {
+      phase_c();
+      phase_a();
+      phase_b();
+    }
+  }
+  // ---- this workgroup's dw2 | db2: threads that own the same column chunk meet in LDS
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e2 = 0; e2 < 8; ++e2) atomicAdd(sRedW + bcc[j] * 8 + e2, myacc[j * 4096 + e2]);
+  __syncthreads();
+  for (int c = tid; c < q; c += 512) prow_out[c] = sRedW[c];
+  if (tid == 0) prow_out[q] = accb;
+}
+
 template <int EPI, int NT16, bool PK, int WM>
 int launch_nt_dma_w(const RowSrc& A, const void* B, int ldb, int M, int N, int K, const EpiArgs& ep, hipStream_t stream) {
   constexpr int DBM = 64 * WM, NP = DBM / 16 + NT16, STAGE = NP * 1024, NS = dma_ring_stages(STAGE, WM);
@@ -2919,6 +3282,46 @@ int nr_launch_pool_fused_fwd(const void* x, int ldx, const void* w1, int ldw1, c
   NrProfScope ps(stream, needed ? "pool_fused_fwd_needed[bf16,n=%d,L=%d,N=%d,q=%d]" : "pool_fused_fwd[bf16,n=%d,L=%d,N=%d,q=%d]", n, L, N, q);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a, max_steps);
   NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
+int nr_pool_fused_bwd_ok(int dtype, int n, int L, int N, int q, int ldw1t) {
+  return !nr_opt(NR_OPT_NO_POOL_FUSED) && dtype == NR_BF16 && L >= 24 && L <= 32 && N > 384 && N <= 416 && N % 8 == 0 && q > 192 && q <= 224 &&
+         q % 8 == 0 && ldw1t >= 224 && (long)n * L >= 4096;
+}
+
+// partial: [>= grid rows][q + 1]; *grid_out = rows written (the caller sums them)
+int nr_launch_pool_fused_bwd(const void* x, int ldx, const void* e, int lde, const float* alpha, const float* g, int ldg, const float* w2,
+                             const void* w1t, int ldw1t, void* dpre, int ldp, void* dx, int lddx, float* partial, int partial_rows,
+                             const int32_t* nz, int n, int L, int N, int q, hipStream_t stream, int* grid_out, int dx_far_unwritten) {
+  constexpr int KS = 13, KS2 = 7;
+  using Cfg = PoolFusedBwdCfg<KS, KS2>;
+  NR_CHECK_ARG(nr_pool_fused_bwd_ok(NR_BF16, n, L, N, q, ldw1t) && ldx >= N && ldx % 8 == 0 && lde >= q && lde % 8 == 0 && ldp >= q && ldp % 8 == 0 &&
+                   lddx >= N && lddx % 8 == 0 && ldg >= N && ldg % 4 == 0 &&
+                   ((((uintptr_t)x) | ((uintptr_t)e) | ((uintptr_t)w1t) | ((uintptr_t)dpre) | ((uintptr_t)dx) | ((uintptr_t)g)) & 15) == 0,
+               "pool_fused_bwd: shape / alignment not eligible");
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, c = 0;
+    NR_CHECK_HIP(hipGetDevice(&dev));
+    NR_CHECK_HIP(hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev));
+    cus = c >= 8 ? c : 256;
+  }
+  int grid = n < cus ? n : cus;                          // one persistent workgroup per CU
+  if (grid > partial_rows) grid = partial_rows;
+  const int max_steps = (n + grid - 1) / grid;
+  const size_t smem = (size_t)Cfg::LIST + (size_t)(max_steps + 8) * sizeof(int);
+  NR_CHECK_ARG(smem <= 160 * 1024, "pool_fused_bwd: %d sequences per workgroup do not fit the LDS list", max_steps);
+  PoolFusedBwdArgs a;
+  a.x = (const bf16_t*)x; a.ldx = ldx; a.e = (const bf16_t*)e; a.lde = lde; a.alpha = alpha; a.g = g; a.ldg = ldg; a.w2 = w2;
+  a.w1t = (const bf16_t*)w1t; a.ldw1t = ldw1t; a.dpre = (bf16_t*)dpre; a.ldp = ldp; a.dx = (bf16_t*)dx; a.lddx = lddx; a.partial = partial;
+  a.nz = nz; a.n = n; a.L = L; a.N = N; a.q = q; a.dx_far_unwritten = (nz != nullptr && dx_far_unwritten) ? 1 : 0;
+  auto kern = pool_fused_bwd_kernel<KS, KS2>;
+  NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  NrProfScope ps(stream, "pool_fused_bwd[bf16,n=%d,L=%d,N=%d,q=%d]", n, L, N, q);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, a, 32 / L + 2);
+  NR_CHECK_LAUNCH();
+  *grid_out = grid;
   return NR_OK;
 }
 

@@ -593,6 +593,14 @@ int nr_launch_pool_core_bwd(int dtype, const void* x, const void* e, const float
   return NR_OK;
 }
 
+// out[c] += column sums of in[rows, cols] for c < split, out2[c - split] for the rest (the pooling backward's dw2 | db2)
+int nr_launch_colsum_split(const float* in, int rows, int cols, int ld, float* out, int split, float* out2, hipStream_t s) {
+  const int ysplit = rows >= 512 ? 32 : (rows >= 64 ? 8 : 1);
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, ysplit), dim3(256), 0, s, in, rows, cols, ld, out, split, out2);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
+
 namespace {
 __global__ __launch_bounds__(256) void fix_flush_kernel(float* __restrict__ out, long long* __restrict__ fix, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {

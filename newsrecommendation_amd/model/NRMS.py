@@ -35,7 +35,9 @@ class NewsEncoder(nn.Module):
                                                               self.attn.att_fc1.out_features, ops.dtype_code(self.attn.compute_dtype))
         y = self.multi_head_self_attn.forward_gather(x, self.embedding_matrix.weight, mask=mask, p_in=p, p_out=p, needed=needed,
                                                      far_unwritten=far)
-        return self.attn(y, mask, needed=needed)
+        # ... and in the other direction: the MHSA backward of a compactly stored batch ignores the dy rows of zero-gradient
+        # sequences, so the pooling need not zero-fill them either
+        return self.attn(y, mask, needed=needed, lazy_dx=far and getattr(y, "_nr_takes_lazy_dy", False))
 
 
 class UserEncoder(nn.Module):

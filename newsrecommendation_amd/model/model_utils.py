@@ -20,14 +20,16 @@ class AttentionPooling(nn.Module):
         self.att_fc2 = nn.Linear(hidden_size, 1)
         self.compute_dtype = compute_dtype
 
-    def forward(self, x, attn_mask=None, needed=None):
+    def forward(self, x, attn_mask=None, needed=None, lazy_dx=False):
         """x: [batch, L, emb]; attn_mask: [batch, L] -> [batch, emb] (fp32).
-        needed (beyond the reference): optional [batch] int32 flags, 0 = the caller multiplies this row's vector by zero."""
+        needed (beyond the reference): optional [batch] int32 flags, 0 = the caller multiplies this row's vector by zero.
+        lazy_dx: see ops.additive_pool (only for an x that comes straight from ops.mhsa and feeds nothing else)."""
         code = ops.dtype_code(self.compute_dtype)
         if x.dtype != ops.torch_dtype(code):
             x = ops.to_compute(x.float(), code)
+            lazy_dx = False
         return ops.additive_pool(x, self.att_fc1.weight, self.att_fc1.bias, self.att_fc2.weight, self.att_fc2.bias,
-                                 code, mask=attn_mask, needed=needed)
+                                 code, mask=attn_mask, needed=needed, lazy_dx=lazy_dx)
 
 
 class ScaledDotProductAttention(nn.Module):

@@ -113,23 +113,31 @@ def _enter_backward() -> int:
     return _bwd_seq
 
 
-def _offer_flags(seq, dx, n, flags_ptr, keepalive) -> None:
+def _offer_flags(seq, dx, n, flags_ptr, keepalive, lazy=False) -> None:
+    """lazy: the dx rows of sequences whose flag is 0 are zeros only NEAR flagged ones and unwritten memory elsewhere
+    (nr_pool_desc.dx_far_unwritten): the taker must be told, and a consumer that cannot take the flags must not read dx."""
     global _flag_hint
+    if dx is not None:
+        dx._nr_lazy_rows = bool(lazy)
     # dx._version: autograd may ADD another consumer's gradient into dx in place (same pointer, same size) before the next
     # libnrhip backward sees it -- the flags would then drop sequences whose gradient is no longer zero
-    _flag_hint = ((seq, dx.data_ptr(), dx.numel(), n, flags_ptr, keepalive, dx._version, weakref.ref(dx))
+    _flag_hint = ((seq, dx.data_ptr(), dx.numel(), n, flags_ptr, keepalive, dx._version, weakref.ref(dx), bool(lazy))
                   if flags_ptr and dx is not None else None)
 
 
 def _take_flags(seq, dy, n):
-    """(device pointer, keep-alive tensor) of the [n] flags for `dy`, or (0, None)."""
+    """(device pointer, keep-alive tensor, lazy) of the [n] flags for `dy`, or (0, None, False)."""
     global _flag_hint
     h, _flag_hint = _flag_hint, None
     if h is not None and h[0] == seq - 1 and h[1] == dy.data_ptr() and h[2] == dy.numel() and h[3] == n:
         dx = h[7]()
         if dx is not None and dx._version == h[6] and dy._version == h[6]:
-            return h[4], h[5]
-    return 0, None
+            return h[4], h[5], h[8]
+    if getattr(dy, "_nr_lazy_rows", False):
+        raise RuntimeError("this gradient was produced with unwritten rows for zero-gradient sequences (additive_pool lazy_dx=True) "
+                           "but the flags that say which ones did not reach its consumer: something else ran between the two backward "
+                           "calls -- construct the pooling with lazy_dx=False")
+    return 0, None, False
 
 
 # Deterministic mode (nr_set_deterministic): gradients that several workgroups add into are accumulated in fixed point with
@@ -393,6 +401,7 @@ class MHSAFunction(Function):
         fused = bool(_lib.lib().nr_mhsa_fwd_fused(C.byref(d)))
         qkv = None if (fused and not need_bwd) else _scratch(n * L, 3 * N, dtype=torch_dtype(code), device=dev)
         check(_lib.lib().nr_mhsa_fwd(C.byref(d), ptr(qkv), ptr(y), _stream()), "nr_mhsa_fwd")
+        cfg["compact_rows"] = bool(keep_rows and _lib.lib().nr_mhsa_compact_rows(C.byref(d)))    # (read by ops.mhsa after apply)
         ctx.cfg, ctx.dims = cfg, (n, L, N, d_model, heads, d_head, ldx, gather)
         ctx.row_ws = row_ws      # the backward attention and the table-gradient GEMM reuse the compaction
         ctx.save_for_backward(src, ids, mask_c, w_p, b_p, wcat, qkv, x_rows)
@@ -408,7 +417,7 @@ class MHSAFunction(Function):
         dy = dy.contiguous()
         if dy.dtype != torch_dtype(code):
             dy = dy.to(torch_dtype(code))
-        seq_nz, seq_nz_owner = _take_flags(seq, dy, n)
+        seq_nz, seq_nz_owner, dy_lazy = _take_flags(seq, dy, n)
         dqkv = _scratch(*qkv.shape, dtype=qkv.dtype, device=dev)
         bucket = cfg.get("flat")
         if bucket is not None:
@@ -426,6 +435,7 @@ class MHSAFunction(Function):
                           mask=ptr(mask_c), w_qkv=ptr(w_p), ldw=w_p.shape[1], b_qkv=ptr(b_p),
                           x_rows=ptr(x_rows), ld_rows=x_rows.shape[1] if x_rows is not None else 0,
                           table_rows=cfg["table_shape"][0] if gather else 0, seq_nz=seq_nz, row_ws_ready=int(ws_ready),
+                          dy_far_unwritten=int(dy_lazy),
                           seq_needed=ptr(cfg.get("needed")))     # (the forward may have left far all-padding x_rows unwritten)
         if need_x:
             w_t = pack(wcat, code, transpose=True)                     # [d_model, 3N]
@@ -522,7 +532,11 @@ def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int, code: int, mask=None, ids=None, 
         if table.requires_grad and torch.is_grad_enabled():
             cfg["table_grad"] = grad_target(table)
             cfg["table_grad_ready"] = getattr(table, "_nr_grad_ready", None)     # parallel.FlatBucket, world > 1
-        return MHSAFunction.apply(table, wq, bq, wk, bk, wv, bv, ids, mask, cfg)
+        y = MHSAFunction.apply(table, wq, bq, wk, bk, wv, bv, ids, mask, cfg)
+        # the backward of this call will ignore the dy rows of sequences flagged "zero gradient" (compact row storage): a pooling
+        # that consumes y alone may leave them unwritten (additive_pool lazy_dx)
+        y._nr_takes_lazy_dy = bool(cfg.get("compact_rows"))
+        return y
     ch = chunk(code)
     if x.shape[-1] % ch:
         # d_model not a multiple of the 16-byte operand chunk: zero-pad the feature axis of x and of the weights (torch
@@ -588,7 +602,7 @@ class PoolFunction(Function):
     """K5: AttentionPooling.forward, src/model/model_utils.py:13-31."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, mask, code, needed=None):
+    def forward(ctx, x, w1, b1, w2, b2, mask, code, needed=None, lazy_dx=False):
         _need_gpu(x, w1, mask)
         n, L, N = x.shape
         q = w1.shape[0]
@@ -607,6 +621,7 @@ class PoolFunction(Function):
         check(_lib.lib().nr_additive_pool_fwd(C.byref(d), ptr(e), ptr(alpha), ptr(out), N, _stream()), "nr_additive_pool_fwd")
         ctx.code, ctx.dims = code, (n, L, N, q)
         ctx.needed = needed
+        ctx.lazy_dx = bool(lazy_dx)
         # (Function.forward runs with grad mode off: no torch.is_grad_enabled() test here -- it would always say no)
         ctx.targets = tuple(grad_target(p) for p in (w1, b1, w2, b2))
         ctx.save_for_backward(x, mask_c, w1_p, b1_c, w2_c, b2_c, e, alpha, w1)
@@ -630,21 +645,25 @@ class PoolFunction(Function):
             dw1, db1, dw2, db2 = flat[:q * N].view(q, N), flat[q * N:q * N + q], flat[q * N + q:q * N + 2 * q], flat[q * N + 2 * q:q * N + 2 * q + 1]
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         d = _lib.PoolDesc(n=n, L=L, N=N, q=q, dtype=code, x=ptr(x), mask=ptr(mask_c), w1=ptr(w1_p), ldw1=w1_p.shape[1],
-                          b1=ptr(b1_c), w2=ptr(w2_c), b2=ptr(b2_c), seq_needed=ptr(ctx.needed))
+                          b1=ptr(b1_c), w2=ptr(w2_c), b2=ptr(b2_c), seq_needed=ptr(ctx.needed), dx_far_unwritten=int(ctx.lazy_dx))
         partial = _ws(_lib.lib().nr_pool_workspace_bytes(C.byref(d)), dev)      # per-workgroup partial rows + slab scratch
         d.partial_bytes = partial.numel() * 4
         check(_lib.lib().nr_additive_pool_bwd(C.byref(d), ptr(e), ptr(alpha), ptr(g), N, ptr(w1_t),
                                               w1_t.shape[1] if w1_t is not None else 0, ptr(dpre), ptr(partial), ptr(dw1),
                                               ptr(db1), ptr(dw2), ptr(db2), ptr(dx), _stream()), "nr_additive_pool_bwd")
-        _offer_flags(seq, dx, n, _lib.lib().nr_pool_seq_flags(C.byref(d), ptr(partial)), partial)
+        flags_ptr = _lib.lib().nr_pool_seq_flags(C.byref(d), ptr(partial))
+        _offer_flags(seq, dx, n, flags_ptr, partial, lazy=ctx.lazy_dx and bool(flags_ptr))
         if direct:
-            return dx, None, None, None, None, None, None, None
-        return dx, dw1, db1, dw2.view(1, q), db2, None, None, None
+            return dx, None, None, None, None, None, None, None, None
+        return dx, dw1, db1, dw2.view(1, q), db2, None, None, None, None
 
 
-def additive_pool(x, w1, b1, w2, b2, code: int, mask=None, needed=None):
-    """needed: optional [n] int32 flags (needed_flags): flag 0 = the pooled vector is not used: zeros, nothing computed."""
-    return PoolFunction.apply(x, w1, b1, w2, b2, mask, code, needed)
+def additive_pool(x, w1, b1, w2, b2, code: int, mask=None, needed=None, lazy_dx=False):
+    """needed: optional [n] int32 flags (needed_flags): flag 0 = the pooled vector is not used: zeros, nothing computed.
+    lazy_dx: the gradient wrt x may keep UNWRITTEN rows for sequences with a zero pooled gradient that lie far from every
+    sequence with one -- only when x is the output of ops.mhsa (gather source) whose `_nr_takes_lazy_dy` is set and nothing
+    else consumes x; the MHSA backward then never reads those rows (and raises if the flags did not reach it)."""
+    return PoolFunction.apply(x, w1, b1, w2, b2, mask, code, needed, bool(lazy_dx) and x.requires_grad)
 
 
 # ------------------------------------------------------------------------------------------ pad blend / cast
@@ -773,7 +792,9 @@ class ConvFunction(Function):
         dy = dy.contiguous()
         if dy.dtype != torch_dtype(code):
             dy = dy.to(torch_dtype(code))
-        seq_nz, seq_nz_owner = _take_flags(seq, dy, n)
+        seq_nz, seq_nz_owner, _lazy = _take_flags(seq, dy, n)
+        if _lazy:
+            raise RuntimeError("conv1d_k3 backward cannot take a gradient with unwritten rows (additive_pool lazy_dx=True)")
         dwp = torch.zeros(N, 3 * Dp, dtype=torch.float32, device=dev)
         direct = all(t is not None for t in ctx.targets)
         db = ctx.targets[1] if direct else torch.zeros(N, dtype=torch.float32, device=dev)

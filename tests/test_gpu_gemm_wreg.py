@@ -192,15 +192,21 @@ def test_sorted_scatter_is_bit_identical_to_batch_order_in_deterministic_mode():
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("n,L,q", [(160, 30, 200), (211, 24, 200), (137, 32, 200), (150, 30, 136), (2048, 30, 200)])
+@pytest.mark.parametrize("n,L,q,masked", [(160, 30, 200, False), (211, 24, 200, False), (137, 32, 200, False), (150, 30, 136, False),
+                                           (2048, 30, 200, False), (1024, 30, 200, True), (800, 24, 208, False), (641, 32, 224, False),
+                                           (640, 32, 224, True)])
 @pytest.mark.parametrize("flags", ["none", "mixed", "all_dead"])
-def test_fused_pooling_forward_against_the_two_kernel_path(n, L, q, flags):
+def test_fused_pooling_forward_against_the_two_kernel_path(n, L, q, masked, flags):
     """pool_fused_fwd_kernel (round 3): fc1 + tanh + fc2 + softmax + weighted sum in one pass over x, a stage = one sequence
     (32 rows: the L real ones + 32 - L rows of the NEXT sequence riding along), software-pipelined over three sequences.
     Against the fc1 GEMM + pool_core_fwd pair (`NO_POOL_FUSED` = 1) and against fp64: out, alpha-dependent gradients and e-
     dependent gradients (the backward reads the e and alpha the forward wrote).  The x rows of unneeded sequences hold 1e30:
     they ride along in their neighbours' stages (and n * L is no multiple of 32: the last stage is clamped) and must not leak.
-    Sequence counts that leave workgroups with 0, 1, 2 and many steps; q below a full column group."""
+    Sequence counts that leave workgroups with 0, 1, 2 and many steps; q below a full column group.
+    The rows-multiple-of-32 cases with >= 16 384 rows also take the fused BACKWARD core (pool_fused_bwd_kernel: dA on the matrix
+    cores from x fragments loaded straight into registers, dpre written in place over e in the LDS ring and to global memory,
+    dX from the ring, dw2 / db2 partial sums); `masked` keeps the forward on the two-kernel path (the fused forward takes no
+    mask) and the backward on the fused one (it needs none: alpha carries it)."""
     g = torch.Generator(device=DEV).manual_seed(n * L + q)
     N = 400
     assert n * L >= 4096
@@ -216,6 +222,10 @@ def test_fused_pooling_forward_against_the_two_kernel_path(n, L, q, flags):
         needed = ops.needed_flags(keep)
         x[~keep] = 1e30        # (finite: at these sizes the backward's dense dW1 = dpre^T . x multiplies these rows by exact zeros)
     gout = torch.randn(n, N, device=DEV, generator=g) * keep.float().unsqueeze(1)
+    mask = None
+    if masked:
+        mask = (torch.rand(n, L, device=DEV, generator=g) < 0.8).float()
+        mask[:, 0] = 1
 
     def run():
         xx = x.clone().requires_grad_(True)
@@ -224,18 +234,24 @@ def test_fused_pooling_forward_against_the_two_kernel_path(n, L, q, flags):
         _lib.prof_enable(1)
         try:
             _lib.prof_collect()
-            out = ops.additive_pool(xx, w1, b1, w2, b2, ops.NR_BF16, mask=None, needed=needed)
+            out = ops.additive_pool(xx, w1, b1, w2, b2, ops.NR_BF16, mask=mask, needed=needed)
+            out.backward(gout)
+            torch.cuda.synchronize()
             labels = set(_lib.prof_collect().keys())
         finally:
             _lib.prof_enable(0)
-        out.backward(gout)
         return labels, (out.detach(), xx.grad.detach().float()[keep], w1.grad.clone(), b1.grad.clone(), w2.grad.clone(), b2.grad.clone())
 
     lab1, got = run()
     with _opt("NO_POOL_FUSED", 1):
         lab0, old = run()
-    assert any(l.startswith("pool_fused_fwd") for l in lab1) and not any(l.startswith("pool_core_fwd") for l in lab1)
-    assert any(l.startswith("pool_core_fwd") for l in lab0) and not any(l.startswith("pool_fused_fwd") for l in lab0)
+    has = lambda labs, p: any(l.startswith(p) for l in labs)
+    assert has(lab1, "pool_fused_fwd") != masked and has(lab1, "pool_core_fwd") == masked
+    assert has(lab0, "pool_core_fwd") and not has(lab0, "pool_fused_fwd") and not has(lab0, "pool_fused_bwd")
+    if (n * L) % 32 == 0 and n * L >= 16384 and 192 < q <= 224:
+        assert has(lab1, "pool_fused_bwd") and not has(lab1, "pool_core_bwd")
+    else:
+        assert has(lab1, "pool_core_bwd") and not has(lab1, "pool_fused_bwd")
     for nm, a, b in zip(["out", "dx", "dw1", "db1", "dw2", "db2"], got, old):
         assert torch.isfinite(a).all(), nm
         if a.numel() == 0:
@@ -247,7 +263,7 @@ def test_fused_pooling_forward_against_the_two_kernel_path(n, L, q, flags):
         assert (a - b).abs().max().item() <= tol, (nm, (a - b).abs().max().item(), scale)
     if keep.any():
         xr = torch.where(keep[:, None, None], x, torch.zeros_like(x))
-        ref = _pool_ref(xr, _bf(w1.detach()), b1.detach(), w2.detach(), b2.detach(), None)
+        ref = _pool_ref(xr, _bf(w1.detach()), b1.detach(), w2.detach(), b2.detach(), mask)
         assert (got[0][keep].double() - ref[keep]).abs().max().item() <= 1e-2 * ref[keep].abs().max().item() + 1e-4
     if (~keep).any():
         assert got[0][~keep].abs().max().item() == 0.0

@@ -72,8 +72,9 @@ TOL = {"fp32": dict(tol=1e-4, gatol=1e-6, grtol=2e-4), "bf16": dict(tol=3e-2, ga
 
 # every size-gated kernel of the benchmarked bf16 step (round-1 and round-2 paths alike): the launch log must show them
 # (round 3: compact row storage -- the live rows only in x_rows / dqkv: rows_materialize_live, attn_mfma_bwd_rows, gemm_tn3_rows)
-STEP_KERNELS = ("gemm_tn3_live", "gemm_tn3_rows", "attn_mfma_bwd_rows", "gemm_nt_dma_live", "attn_mfma_fwd_live", "needed_list", "pool_core_bwd",
-                "gemm_nt_wreg_live", "gemm_nt_wreg_needed", "rows_materialize_live", "sort_rows_by_id")
+#  fused additive pooling: pool_fused_fwd, pool_fused_bwd)
+STEP_KERNELS = ("gemm_tn3_live", "gemm_tn3_rows", "attn_mfma_bwd_rows", "gemm_nt_dma_live", "attn_mfma_fwd_live", "needed_list", "pool_fused_fwd",
+                "pool_fused_bwd", "gemm_nt_wreg_live", "rows_materialize_live", "sort_rows_by_id")
 
 
 def _nrms_against_the_oracle(dt, train, B, V, seed):
