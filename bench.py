@@ -218,6 +218,14 @@ def price_kernel(label, avg_ms, struct, dtype):
             if name.endswith("_live"):
                 by *= struct["attention_bwd_sequences"]
         return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}
+    if name.startswith("pool_fused"):
+        # one pass per sequence that is needed (forward) / has a pooled gradient (backward): x in; e out (forward), or e in and
+        # dpre + dX out (backward); out / alpha / g rows are small
+        n, L, N, q = _dims(label, r"n=(\d+),L=(\d+),N=(\d+),q=(\d+)")
+        frac = struct.get("needed_titles", 1.0)
+        per_row = (N + q) if "fwd" in name else (N + q + q + N)
+        by = n * frac * L * per_row * esz
+        return {"bound": "hbm", "achieved": round(by / s / 1e9, 1), "peak": PEAK_HBM, "unit": "GB/s", "work": by}
     if name.startswith("pool_core"):
         n, L, N, q = _dims(label, r"n=(\d+),L=(\d+),N=(\d+),q=(\d+)")
         by = n * L * (N + q) * esz * (1 if "fwd" in name else 1) + n * L * q * esz * (0 if "fwd" in name else 1)

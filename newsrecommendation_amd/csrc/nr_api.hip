@@ -981,7 +981,8 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
   const int32_t* zero_flags = ws != nullptr ? ws : d->seq_needed;
   // title-level shapes with slab flags and an input gradient asked for: dA, ds, dpre, dX and the dw2 / db2 partial sums in ONE
   // kernel (x and e read once, dpre never read back for dX); the weight gradient dW1 = dpre^T . x below is unchanged
-  if (ws != nullptr && dx != nullptr && w1_t != nullptr && nr_pool_fused_bwd_ok(d->dtype, d->n, d->L, d->N, d->q, ldw1t) && ld_g % 4 == 0 &&
+  // (not in deterministic mode: the kernel adds its threads' dw2 partial sums with LDS float atomics)
+  if (ws != nullptr && dx != nullptr && w1_t != nullptr && !det.on() && nr_pool_fused_bwd_ok(d->dtype, d->n, d->L, d->N, d->q, ldw1t) && ld_g % 4 == 0 &&
       ((((uintptr_t)d->x) | ((uintptr_t)e) | ((uintptr_t)w1_t) | ((uintptr_t)dpre) | ((uintptr_t)dx) | ((uintptr_t)g)) & 15) == 0 && d->N % 8 == 0) {
     int rows = 0;
     if ((rc = nr_launch_pool_fused_bwd(d->x, d->N, e, d->q, alpha, g, ld_g, d->w2, w1_t, ldw1t, dpre, d->q, dx, d->N, partial,

@@ -347,4 +347,6 @@ def test_deterministic_mode_gives_bit_identical_gradients(model_name):
             # weight-gradient GEMM over per-token rows: two summations of the same bf16-rounded factors
             assert float((g1[k] - plain[k]).abs().max()) <= 2e-3 * float(plain[k].abs().max()) + 3e-4, k
             continue
-        assert float((g1[k] - plain[k]).abs().max()) <= 1e-5 * float(plain[k].abs().max()) + 1e-8, k
+        # (the default run also takes the fused pooling backward -- dA on the matrix cores from bf16 hi + lo factors, dpre and dX
+        #  from one kernel -- where this mode runs the two-kernel path: a bf16 rounding of dpre / dX flips here and there)
+        assert float((g1[k] - plain[k]).abs().max()) <= 1e-3 * float(plain[k].abs().max()) + 1e-8, k
