@@ -271,7 +271,8 @@ def pmc_traffic(label, workload=None):
         return None
     key = {"gemm_nt[": "gemm_nt_kernelIDF16bLi0ELi0", "gemm_nt_dma": "gemm_nt_dma_kernel", "gemm_nt_wreg": "gemm_nt_wreg_kernel", "gemm_tn2": "tn2::gemm_tn2_kernel", "gemm_tn3": "tn3::gemm_tn3_kernel",
            "attn_mfma_bwd": "b16::bwd_kernel", "attn_mfma_fwd": "b16::fwd_kernel", "gemm_nt_wide": "gemm_nt_wide_kernel",
-           "mhsa_fused_fwd": "fused_fwd", "mhsa_fused_bwd": "fused_bwd"}
+           "mhsa_fused_fwd": "fused_fwd", "mhsa_fused_bwd": "fused_bwd", "pool_fused_fwd": "pool_fused_fwd_kernel",
+           "pool_fused_bwd": "pool_fused_bwd_kernel", "rows_materialize_live": "gather_live_rows_kernel"}
     want = next((v for k, v in key.items() if label.startswith(k)), None)
     if want is None:
         return None
