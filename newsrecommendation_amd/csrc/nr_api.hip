@@ -47,7 +47,7 @@ struct OptDef { const char* name; int def; };
 const OptDef g_opt_defs[NR_OPT_COUNT] = {
     {"NO_SLABS", 0},   {"NO_ATTN_SKIP", 0}, {"SIDE_STREAM", 0}, {"ATTN_OLD", 0},  {"ATTN_VALU", 0},   {"NO_PAD_SUB", 0},
     {"NO_FUSED_FWD", 0}, {"NO_TN3", 0},     {"TN_V1", 0},       {"TN3_ROUNDS", 0}, {"TN3_WK", 0},      {"TN3_NI", 0},
-    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}, {"NO_ROW_SUB", 0}, {"ATTN_BWD_OCC4", 0}, {"NT_ABLATE", 0}, {"NT_WREG", 1}, {"NO_SCATTER_SORT", 0}, {"TN3_MIN_M", 16384}, {"NO_COMPACT_ROWS", 0}, {"NO_POOL_FUSED", 0}, {"ATTN_BWD_GRID", 0}, {"POOL_ABLATE", 0}};
+    {"NT_NOWIDE", 0},  {"NT_NODMA", 0},     {"DMA_MIN_K", 192}, {"DMA_WM2_ALL", 0}, {"ATTN_PRED", 0}, {"ATTN_GENERIC", 0}, {"NO_ROW_SUB", 0}, {"ATTN_BWD_OCC4", 0}, {"NT_ABLATE", 0}, {"NT_WREG", 1}, {"NO_SCATTER_SORT", 0}, {"TN3_MIN_M", 16384}, {"NO_COMPACT_ROWS", 0}, {"NO_POOL_FUSED", 0}, {"ATTN_BWD_GRID", 0}, {"TN3_ATOMIC", 0}, {"TN3_ABLATE", 0}, {"POOL_ABLATE", 0}};
 std::atomic<int> g_opt[NR_OPT_COUNT];
 std::once_flag g_opt_once;
 void opt_init() {
@@ -286,10 +286,10 @@ static int mhsa_rows(const nr_mhsa_desc* d, RowSrc* out) {
 // row_ws (int32): [0,4) counters | M live rows | M their ids | M padding rows | n per-sequence live-token masks |
 //                 slab scratch: n title flags, 4 counters, M/32 slab ids, 4 pad | sequence list: 4 counters, n entries
 struct MhsaWs {
-  size_t live_idx, live_ids, dead_idx, tmask, slab, seq, sort_idx, sort_ids, hist, pos, sort_k, dump, total;   // offsets in int32 elements
+  size_t live_idx, live_ids, dead_idx, tmask, slab, seq, sort_idx, sort_ids, hist, pos, sort_k, dump, tn_scratch, tn_floats, total;   // offsets in int32 elements
 };
 // table_rows > 0 (gather source): room for the live rows sorted by token id (table-gradient scatter) and its histogram
-static MhsaWs mhsa_ws_layout(int n, int L, int table_rows) {
+static MhsaWs mhsa_ws_layout(int n, int L, int table_rows, int N3 = 0, int Kp = 0) {
   const size_t M = (size_t)n * L;
   MhsaWs w;
   w.live_idx = 4; w.live_ids = 4 + M; w.dead_idx = 4 + 2 * M; w.tmask = 4 + 3 * M;
@@ -303,15 +303,30 @@ static MhsaWs mhsa_ws_layout(int n, int L, int table_rows) {
   w.pos = (w.hist + (table_rows > 0 ? (size_t)table_rows + 8 : 0) + 3) / 4 * 4;
   w.sort_k = w.pos + (table_rows > 0 ? (M + 3) / 4 * 4 : 0);
   w.dump = w.sort_k + (table_rows > 0 ? (M + 3) / 4 * 4 : 0);
-  w.total = w.dump + (table_rows > 0 ? 1024 : 0);
+  // partial tiles of the weight-gradient GEMM's splits (fp32; see nr_launch_gemm_tn_slabs): store + reduce instead of atomics
+  w.tn_scratch = (w.dump + (table_rows > 0 ? 1024 : 0) + 3) / 4 * 4;
+  w.tn_floats = (table_rows > 0 && N3 >= 8 && Kp >= 8 && M % 32 == 0) ? nr_gemm_tn_scratch_floats((int)M, N3, Kp) : 0;
+  w.total = w.tn_scratch + w.tn_floats;
   return w;
+}
+static MhsaWs mhsa_ws_of(const nr_mhsa_desc* d) {
+  const bool gather = d->src_kind == NR_SRC_GATHER;
+  const int ch = dtype_ok(d->dtype) ? nr_chunk(d->dtype) : 4;
+  return mhsa_ws_layout(d->n, d->L, gather ? d->table_rows : 0, gather && d->dtype == NR_BF16 ? 3 * d->heads * d->d_head : 0,
+                        gather && d->dtype == NR_BF16 ? round_up(d->d_model, ch) : 0);
 }
 // bwd_ws of the convolution (int32): n title flags | 4 counters | M/32 slab ids | pad
 static size_t conv_ws_elems(int n, int T) { return (size_t)n + 4 + ((size_t)n * T) / 32 + 12; }
 int nr_pool_partial_rows(int n);
 // `partial` of the pooling backward (fp32): nr_pool_partial_rows(n) rows of (q+1) | int32 scratch: n flags, 4 counters, M/32 slabs
 static size_t pool_ws_used(int n, int q) { return ((size_t)nr_pool_partial_rows(n) * (q + 1) + 3) / 4 * 4; }
-static size_t pool_ws_elems(int n, int L, int q) { return pool_ws_used(n, q) + (size_t)n + 8 + ((size_t)n * L) / 32 + 4; }
+static size_t pool_ws_ints(int n, int L, int q) { return (pool_ws_used(n, q) + (size_t)n + 8 + ((size_t)n * L) / 32 + 4 + 3) / 4 * 4; }
+// ... | fp32 partial tiles of the att_fc1 weight-gradient GEMM's splits (store + reduce epilogue, nr_launch_gemm_tn_slabs)
+static size_t pool_tn_floats(int n, int L, int q, int N, int dtype) {
+  const size_t M = (size_t)n * L;
+  return (dtype == NR_BF16 && q >= 8 && N >= 8 && M % 32 == 0 && M > 0) ? nr_gemm_tn_scratch_floats((int)M, q, N) : 0;
+}
+static size_t pool_ws_elems(int n, int L, int q, int N = 0, int dtype = NR_F32) { return pool_ws_ints(n, L, q) + pool_tn_floats(n, L, q, N, dtype); }
 
 static bool pool_has_flags(const nr_pool_desc* d) {
   const int M = d->n * d->L;
@@ -353,9 +368,9 @@ static int mhsa_check(const nr_mhsa_desc* d) {
   NR_CHECK_ARG(d->n == 0 || (d->x && d->w_qkv && d->b_qkv), "mhsa: null operand");
   NR_CHECK_ARG(d->p_in >= 0.f && d->p_in < 1.f && d->p_out >= 0.f && d->p_out < 1.f, "mhsa: dropout p out of range");
   NR_CHECK_ARG((uint64_t)d->n * d->L * (uint64_t)(3 * d->heads * d->d_head) < 0xffffffffull, "mhsa: problem too large for 32-bit element counters");
-  NR_CHECK_ARG(d->row_ws == nullptr || d->row_ws_bytes >= mhsa_ws_layout(d->n, d->L, d->src_kind == NR_SRC_GATHER ? d->table_rows : 0).total * sizeof(int32_t),
+  NR_CHECK_ARG(d->row_ws == nullptr || d->row_ws_bytes >= mhsa_ws_of(d).total * sizeof(int32_t),
                "mhsa: row_ws holds %zu bytes, nr_mhsa_workspace_bytes() asks for %zu", d->row_ws_bytes,
-               mhsa_ws_layout(d->n, d->L, d->src_kind == NR_SRC_GATHER ? d->table_rows : 0).total * sizeof(int32_t));
+               mhsa_ws_of(d).total * sizeof(int32_t));
   return NR_OK;
 }
 
@@ -448,7 +463,7 @@ int nr_get_option(const char* name) {
 }
 
 size_t nr_mhsa_workspace_bytes(const nr_mhsa_desc* d) {
-  return (d == nullptr || d->n < 0 || d->L < 1) ? 0 : mhsa_ws_layout(d->n, d->L, d->src_kind == NR_SRC_GATHER ? d->table_rows : 0).total * sizeof(int32_t);
+  return (d == nullptr || d->n < 0 || d->L < 1) ? 0 : mhsa_ws_of(d).total * sizeof(int32_t);
 }
 size_t nr_conv_workspace_bytes(const nr_conv_desc* d) {
   return (d == nullptr || d->n < 0 || d->T < 1) ? 0 : conv_ws_elems(d->n, d->T) * sizeof(int32_t);
@@ -457,7 +472,7 @@ int nr_pool_contracts_slabs(const nr_pool_desc* d) {
   return (d != nullptr && d->n > 0 && d->L >= 1 && d->q >= 1 && dtype_ok(d->dtype) && pool_has_flags(d)) ? 1 : 0;
 }
 size_t nr_pool_workspace_bytes(const nr_pool_desc* d) {
-  return (d == nullptr || d->n < 0 || d->L < 1 || d->q < 1) ? 0 : pool_ws_elems(d->n, d->L, d->q) * sizeof(float);
+  return (d == nullptr || d->n < 0 || d->L < 1 || d->q < 1) ? 0 : pool_ws_elems(d->n, d->L, d->q, d->N, d->dtype) * sizeof(float);
 }
 const int32_t* nr_pool_seq_flags(const nr_pool_desc* d, const float* partial) {
   if (d == nullptr || partial == nullptr || d->n <= 0 || d->L < 1 || d->q < 1 || !dtype_ok(d->dtype) || !pool_has_flags(d)) return nullptr;
@@ -578,7 +593,7 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   NR_DEVICE_GUARD(stream, y);
   const int N = d->heads * d->d_head, M = d->n * d->L, Kp = round_up(d->d_model, nr_chunk(d->dtype));
-  const MhsaWs W = mhsa_ws_layout(d->n, d->L, d->src_kind == NR_SRC_GATHER ? d->table_rows : 0);
+  const MhsaWs W = mhsa_ws_of(d);
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
   if (d->proj_table != nullptr) {
@@ -668,7 +683,7 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
   hipStream_t s = (hipStream_t)stream;
   NR_DEVICE_GUARD(stream, dqkv);
   const int N = d->heads * d->d_head, M = d->n * d->L, ch = nr_chunk(d->dtype), Kp = round_up(d->d_model, ch);
-  const MhsaWs W = mhsa_ws_layout(d->n, d->L, d->src_kind == NR_SRC_GATHER ? d->table_rows : 0);
+  const MhsaWs W = mhsa_ws_of(d);
   RowSrc A;
   if ((rc = mhsa_rows(d, &A))) return rc;
   NR_CHECK_ARG(d->bwd_phase >= 0 && d->bwd_phase <= 2, "mhsa_bwd: bwd_phase=%d", d->bwd_phase);
@@ -718,7 +733,8 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
       RowSrc G = dense_rows(dqkv, 3 * N, 3 * N);
       if ((rc = nr_launch_gemm_nt(d->dtype, G, w_qkv_t, ldwt, M, d->d_model, 3 * N, EPI_SCATTER, ep, s))) return rc;
     }
-    if (ph_dw && (rc = nr_launch_gemm_tn_counted(dqkv, 3 * N, d->x_rows, d->ld_rows, dw_qkv, d->d_model, M, 3 * N, Kp, 3 * N, d->d_model, ws, s)))
+    if (ph_dw && (rc = nr_launch_gemm_tn_counted(dqkv, 3 * N, d->x_rows, d->ld_rows, dw_qkv, d->d_model, M, 3 * N, Kp, 3 * N, d->d_model, ws, s,
+                                                 W.tn_floats ? reinterpret_cast<float*>(ws + W.tn_scratch) : nullptr, W.tn_floats)))
       return rc;
     return NR_OK;
   }
@@ -814,7 +830,8 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
   if (ph_dw) {
     if (slab_ws != nullptr) {
       if ((rc = nr_launch_gemm_tn_slabs(dqkv, 3 * N, d->x_rows, d->ld_rows, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model,
-                                        slab_ws + d->n + 4, slab_ws + d->n, s)))
+                                        slab_ws + d->n + 4, slab_ws + d->n, s, 0,
+                                        W.tn_floats ? reinterpret_cast<float*>(d->row_ws + W.tn_scratch) : nullptr, W.tn_floats)))
         return rc;
     } else if ((rc = nr_launch_gemm_tn(d->dtype, dqkv, 3 * N, Xs, dw_qkv, d->d_model, db_qkv, M, 3 * N, Kp, 3 * N, d->d_model, s))) {
       return rc;
@@ -956,9 +973,11 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
   if (d->n == 0) return NR_OK;
   NR_CHECK_ARG(e && alpha && g && dpre && partial && dw1 && db1 && dw2 && db2, "additive_pool_bwd: null operand");
   NR_DEVICE_GUARD(stream, dpre);
-  NR_CHECK_ARG(d->partial_bytes >= pool_ws_elems(d->n, d->L, d->q) * sizeof(float),
+  NR_CHECK_ARG(d->partial_bytes >= pool_ws_elems(d->n, d->L, d->q, d->N, d->dtype) * sizeof(float),
                "additive_pool_bwd: partial holds %zu bytes, nr_pool_workspace_bytes() asks for %zu", d->partial_bytes,
-               pool_ws_elems(d->n, d->L, d->q) * sizeof(float));
+               pool_ws_elems(d->n, d->L, d->q, d->N, d->dtype) * sizeof(float));
+  float* tn_scratch = partial + pool_ws_ints(d->n, d->L, d->q);
+  const size_t tn_floats = pool_tn_floats(d->n, d->L, d->q, d->N, d->dtype);
   hipStream_t s = (hipStream_t)stream;
   const int M = d->n * d->L;
   DetScope det(s);                                   // dw1 / db1 come from the GEMM kernels, dw2 / db2 from the column sums
@@ -990,7 +1009,8 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
       return rc;
     if ((rc = nr_launch_colsum_split(partial, rows, d->q + 1, d->q + 1, dw2, d->q, db2, s))) return rc;
     if ((rc = nr_launch_live_slabs(ws, d->n, d->L, s))) return rc;
-    return nr_launch_gemm_tn_slabs(dpre, d->q, d->x, d->N, dw1, d->N, db1, M, d->q, d->N, d->q, d->N, ws + d->n + 4, ws + d->n, s);
+    return nr_launch_gemm_tn_slabs(dpre, d->q, d->x, d->N, dw1, d->N, db1, M, d->q, d->N, d->q, d->N, ws + d->n + 4, ws + d->n, s, 0,
+                                   tn_floats ? tn_scratch : nullptr, tn_floats);
   }
   if ((rc = nr_launch_pool_core_bwd(d->dtype, d->x, e, d->w2, alpha, g, ld_g, dpre, partial, dw2, db2, d->n, d->L, d->N, d->q, s, zero_flags)))
     return rc;
@@ -1000,7 +1020,8 @@ int nr_additive_pool_bwd(const nr_pool_desc* d, const void* e, const float* alph
   if (fork && (rc = side_fork(s, &s2))) return rc;
   if (ws != nullptr) {
     if ((rc = nr_launch_live_slabs(ws, d->n, d->L, s))) return rc;
-    if ((rc = nr_launch_gemm_tn_slabs(dpre, d->q, d->x, d->N, dw1, d->N, db1, M, d->q, d->N, d->q, d->N, ws + d->n + 4, ws + d->n, s)))
+    if ((rc = nr_launch_gemm_tn_slabs(dpre, d->q, d->x, d->N, dw1, d->N, db1, M, d->q, d->N, d->q, d->N, ws + d->n + 4, ws + d->n, s, 0,
+                                      tn_floats ? tn_scratch : nullptr, tn_floats)))
       return rc;
   } else if ((rc = nr_launch_gemm_tn(d->dtype, dpre, d->q, X, dw1, d->N, db1, M, d->q, d->N, d->q, d->N, s))) {
     return rc;

@@ -99,6 +99,8 @@ enum NrOpt {
   NR_OPT_NO_COMPACT_ROWS, // 1: x_rows / dqkv of the news-level training path keep one row per token (no compact row storage)
   NR_OPT_NO_POOL_FUSED,  // 1: additive pooling forward as fc1 GEMM + pool_core_fwd instead of the fused kernel
   NR_OPT_ATTN_BWD_GRID,  // >0: workgroups of the compact-row attention backward (default 4096 = 16 per CU, grid-stride over the walk)
+  NR_OPT_TN3_ATOMIC,     // 1: the LDS-DMA weight-gradient kernel adds its tiles into dW with fp32 atomics even when the caller brought scratch
+  NR_OPT_TN3_ABLATE,     // measurement only (results are WRONG): 1 = the LDS-DMA weight-gradient kernel skips its fp32 atomic epilogue
   NR_OPT_POOL_ABLATE,    // measurement only (results are WRONG): fused pooling forward without 1: weighted sum, 2: softmax, 4: out reduction, 8: MFMAs, 16: tanh / logit epilogue
   NR_OPT_COUNT
 };

