@@ -569,6 +569,19 @@ __device__ __forceinline__ void mm_xt_T(f32x16& acc, const f32x16& x, const bf16
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc, 0, 0, 0);
   }
 }
+// acc[c][j] += sum_i Bm[i][c] Xi[i][j]: mm_xt_T with the accumulator-tile operand replaced by a ROW-MAJOR image Xi[token i][j]
+// (written by acc_to_img_t from the tile whose lanes own i): both operands contract over tokens through transposed reads
+__device__ __forceinline__ void mm_tt_T(f32x16& acc, const bf16_t* Xi, const bf16_t* Bm, int lane) {
+  const int g16 = lane >> 4, h = g16 >> 1, cb = 16 * (g16 & 1), qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int o0 = ioff(16 * s + 4 * h + qq, cb + 4 * pp), o1 = ioff(16 * s + 8 + 4 * h + qq, cb + 4 * pp);
+    const bf16x4 lo = trd(Bm + o0), hi = trd(Bm + o1), xl = trd(Xi + o0), xh = trd(Xi + o1);
+    const bf16x8 b = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const bf16x8 x = {xl[0], xl[1], xl[2], xl[3], xh[0], xh[1], xh[2], xh[3]};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, x, acc, 0, 0, 0);
+  }
+}
 template <bool DROP>
 __device__ __forceinline__ void acc_t_to_global(const f32x16& acc, bf16_t* __restrict__ dst, int ld, int L, int d, int lane,
                                                 const DropCfg& drop, uint32_t eidx0, uint32_t erow) {
@@ -1084,7 +1097,13 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
     nx.next(hgroups, stride);
     const ItemIter pf = nx.sb < nseq ? nx : it;
     prefetch(pf);
+    // ONE orientation (S^T: the lane owns query i, its registers the keys j, softmax statistics lane-local).  The two
+    // products that contract over QUERIES (dK, dV) used to recompute S, P, dP and dS in the other orientation -- 4 more
+    // MFMAs, 16 more v_exp and ~110 more VALU instructions per item in a kernel that is VALU-issue bound (SQ counters,
+    // profiles/r03a: VALU 3 x 21 % of the SIMD, MFMA 15 %).  Now P and dS go as row-major bf16 images [i][j] into the
+    // wave's V image (dead once dP^T is formed) and come back through the same transposed reads that deliver Q^T and G^T.
     f32x16 dst;  // dS^T (lane = query i), carries the 1/sqrt(d) factor of dQ and dK
+    f32x16 dq, dk, dv;
     {
       f32x16 st, dpt;
 #pragma unroll
@@ -1109,75 +1128,46 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
       }
       sum += __shfl_xor(sum, 32, 64);
       rdu += __shfl_xor(rdu, 32, 64);
-      const float inv = 1.f / (sum + 1e-8f * __builtin_amdgcn_exp2f(-mc));
+      const float eps = 1e-8f * __builtin_amdgcn_exp2f(-mc);
+      const float inv = 1.f / (sum + eps);
       const float rd = rdu * inv;
       const float invs = inv * a.scale;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[r] = st[r] * invs * (dpt[r] - rd);
-      if (lane < 32) {
-        sM[lane] = mc;
-        sInv[lane] = inv;
-        sRd[lane] = rd;
-        if (CPT) {
-          // row sums of query li (0 for the padded queries): sum_j P_ij = rho = 1 - er, sum_j dS_ij = scale * rd * (1 - rho)
-          const float er = 1e-8f * __builtin_amdgcn_exp2f(-mc) * inv;
-          sRs[lane] = li < L ? a.scale * rd * er : 0.f;
-          sRho[lane] = li < L ? 1.f - er : 0.f;
-        }
-      }
-    }
-    __syncthreads();
-    f32x16 dq, dk, dv;
-    {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-      if (!CPT) mm_xt_T(dq, dst, sK, lane); // dQ^T[c][i] = sum_j K[j][c] dS[i][j] / sqrt(d)
-      f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-      mm_rr(s, sQ, sK, lane);     // S[i][j] (unscaled)
-      mm_rr(dp, sG, sV, lane);    // dP[i][j]
-      float mj = (li < L) ? 1.f : 0.f;
-      if (HAS_MASK) mj = sMask[li];
-#pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int i = rowof(r, h2);
-        const float pij = __builtin_amdgcn_exp2f(fmaf(s[r], c1, -sM[i])) * (mj * sInv[i]);
-        s[r] = pij;
-        dp[r] = pij * a.scale * (dp[r] - sRd[i]);
+        dst[r] = st[r] * invs * (dpt[r] - rd);
+        st[r] *= inv;                                    // P^T[j][i]
       }
       if (CPT) {
         // Bias gradient without storing the padding rows: db_q = sum_j (sum_i dS_ij) K_j, db_k = sum_i (sum_j dS_ij) Q_i,
         // db_v = sum_i (sum_j P_ij) G_i.  The three row / column sums travel through the products below as ONE EXTRA token
-        // -- column 31 of the 32 x 32 tiles, free because L <= 31 -- and come out in lanes 31 / 63 of dq / dk / dv:
-        //   dS   column 31 (lane 31, registers = queries i) <- row sums of dS = scale * rd_i * (1 - rho_i)      (sRs, phase 1)
-        //   P    column 31                                  <- rho_i = sum_j P_ij = 1 - 1e-8 * exp2(-m_i c) * inv_i   (sRho)
-        //   dS^T column 31 (lane 31, registers = keys j)    <- column sums of dS   (this lane's registers, via LDS)
-        // dQ is computed LAST here (dS^T stays live instead of dQ across the other two products: same register peak)
-        float cs = 0.f;
+        // -- index 31 of the 32 x 32 tiles, free because L <= 31 -- and come out in lanes 31 / 63 of dq / dk / dv:
+        //   dS[i][31] <- row sum of dS = scale * rd_i * (1 - rho_i), P[i][31] <- rho_i = sum_j P_ij = 1 - eps_i inv_i: the
+        //     lane's own statistics (register 15 of the upper half-wave is key 31; K row 31 is zero, so dQ does not see it)
+        //   Q[i][31] <- 1: row 31 of dK^T then holds the COLUMN sums of dS; they go through LDS into the registers of lanes
+        //     31 / 63 (query 31) before the dQ product, which is therefore computed last
+        const float er = eps * inv;
+        const bool up = h2 != 0;
+        dst[15] = up ? (li < L ? a.scale * rd * er : 0.f) : dst[15];
+        st[15] = up ? (li < L ? 1.f - er : 0.f) : st[15];
+        if (lane < 32) sQ[ioff(lane, 31)] = (bf16_t)1.f;
+      } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cs += dp[r];
-        cs += __shfl_xor(cs, 32, 64);
-        if (lane < 32) sCs[lane] = cs;
-        const bool x31 = li == 31;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {                      // registers 4k .. 4k+3 = queries 8k + 4 h2 .. + 3
-          const f32x4 rs4 = *reinterpret_cast<const f32x4*>(sRs + 8 * k + 4 * h2), rh4 = *reinterpret_cast<const f32x4*>(sRho + 8 * k + 4 * h2);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            dp[4 * k + e] = x31 ? rs4[e] : dp[4 * k + e];
-            s[4 * k + e] = x31 ? rh4[e] : s[4 * k + e];
-          }
-        }
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+        mm_xt_T(dq, dst, sK, lane); // dQ^T[c][i] = sum_j K[j][c] dS[i][j] / sqrt(d)
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
-      mm_xt_T(dk, dp, sQ, lane);  // dK^T[c][j] = sum_i Q[i][c] dS[i][j] / sqrt(d)
-      mm_xt_T(dv, s, sG, lane);   // dV^T[c][j] = sum_i G[i][c] P[i][j]
+      acc_to_img_t(st, 1.f, sV, lane);   // P[i][j]
+      mm_tt_T(dv, sV, sG, lane);         // dV^T[c][j] = sum_i G[i][c] P[i][j]
+      acc_to_img_t(dst, 1.f, sV, lane);  // dS[i][j] (the wave's LDS operations execute in order: the reads above are done)
+      mm_tt_T(dk, sV, sQ, lane);         // dK^T[c][j] = sum_i Q[i][c] dS[i][j] / sqrt(d)
     }
     if (CPT) {
       {
+        if (h2) sCs[li] = dk[15];                          // dK^T[31][j]: column sums of dS
         const bool x31 = li == 31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                      // registers 4k .. 4k+3 = keys 8k + 4 h2 .. + 3 (the wave's own LDS words)
           const f32x4 c4 = *reinterpret_cast<const f32x4*>(sCs + 8 * k + 4 * h2);
