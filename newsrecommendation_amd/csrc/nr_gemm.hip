@@ -1142,7 +1142,8 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
         if (wn * HN + j < NT16) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            if (PK) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0);
+            // (weights on the row side: a lane then owns 4 CONSECUTIVE output columns of one row, see the epilogues)
+            if (PK || EPI == EPI_SCATTER) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[buf][j], fa[buf][i], acc[i][j], 0, 0, 0);
             else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[buf][i], fb[buf][j], acc[i][j], 0, 0, 0);
           }
         }
@@ -1189,7 +1190,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           // PK: weights on the MFMA row side -> a lane owns 4 consecutive output columns of one row
-          if (PK) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
+          if (PK || EPI == EPI_SCATTER) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af[i], acc[i][j], 0, 0, 0);
           else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][j], 0, 0, 0);
         }
       }
@@ -1291,76 +1292,108 @@ __global__ __launch_bounds__(128 * WM) void gemm_nt_dma_kernel(const bf16_t* __r
     return;
   }
   if constexpr (EPI == EPI_SCATTER) {
-    // table-gradient scatter, 64 rows (one wave row) at a time through the fp32 LDS tile.  A wave owns 64 / NW consecutive
-    // rows with its lanes on CONSECUTIVE floats (an atomic instruction covers whole 128-byte lines of the destination
-    // row; float4-per-lane ownership spread every instruction over 8 lines).  Rows that follow each other with the SAME
-    // token id -- the caller hands the rows over sorted by id -- are summed in registers and leave as one atomic row:
-    // memory-side float atomics run at ~1.3 TB/s chip-wide, one atomic row per occurrence was half of this kernel.
-    constexpr int RPW = 64 / NW, NC = (WBN + 63) / 64;
-    static_assert((size_t)64 * SCW * sizeof(float) <= (size_t)NS * STAGE, "scatter tile must fit the ring");
-#pragma unroll 1
-    for (int pass = 0; pass < WM; ++pass) {
-      if (pass) __syncthreads();
-      if (wm == pass) {
+    // Table-gradient scatter, WAVE-LOCAL: every wave stages 16 of its 64 rows x its HN*16 columns in its own block of the
+    // (drained) ring -- 16-byte writes, a lane owns 4 consecutive columns of a row -- and walks those rows itself, lanes on
+    // adjacent column pairs.  No workgroup barrier in the whole epilogue and all 8 waves busy (the shared 64-row tile had 2
+    // waves writing 160 scalar words per lane while 6 waited, 4 times per tile: 0.115 of this kernel's 0.43 ms).  Rows that
+    // follow each other with the SAME token id -- the caller hands the rows over sorted by id -- are summed in registers,
+    // now across all 64 rows of the wave, and leave as one atomic row (memory-side float atomics: ~1.3 TB/s chip-wide).
+    // One dropout hash serves the lane's two columns (the pair hash of nr_keep) when the pair starts on an even element.
+    constexpr int WC = HN * 16, SW = WC + 4, NC2 = (WC + 127) / 128;
+    static_assert((size_t)NW * 16 * SW * sizeof(float) <= (size_t)NS * STAGE, "scatter blocks must fit the ring");
+    float* sW = sC + wid * 16 * SW;
+    const int cw0 = wn * WC;                           // first column of this wave inside the chunk
+    auto scatter = [&](auto det_tag) {
+    constexpr bool DET = decltype(det_tag)::value;     // two bodies: the fixed-point state of the deterministic mode costs the default one its registers
+    float run[NC2][2];
+    long long runq[NC2][2];                            // deterministic mode: the run is summed in fixed point (order independent)
 #pragma unroll
-        for (int j = 0; j < HN; ++j) {
-          const int jt = wn * HN + j;
-          if (jt < NT16) {
-            const int col = jt * 16 + (lane & 15);
+    for (int u = 0; u < NC2; ++u) { run[u][0] = run[u][1] = 0.f; runq[u][0] = runq[u][1] = 0; }
+    int run_id = 0;
+    auto flush = [&]() {
+      if (run_id != 0) {                               // padding_idx row receives no gradient
+        float* dst = (float*)ep.C + (size_t)run_id * ep.ldc + nbase + cw0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int u = 0; u < NC2; ++u)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) sC[(i * 16 + (lane >> 4) * 4 + r) * SCW + col] = acc[i][j][r];
+          for (int e = 0; e < 2; ++e) {
+            const int c = 128 * u + 2 * lane + e;
+            if (c < WC && cw0 + c < N && nbase + cw0 + c < ep.Dtrue) {
+              if (DET) { if (runq[u][e] != 0) nr_accum_fix(dst + c, runq[u][e]); }
+              else if (run[u][e] != 0.f && !((abl & 1) && run[u][e] != 1234.5f)) atomicAdd(dst + c, run[u][e]);
+            }
           }
-        }
       }
-      __syncthreads();
-      float run[NC];
-      long long runq[NC];                            // deterministic mode: the run is summed in fixed point (order independent)
 #pragma unroll
-      for (int u = 0; u < NC; ++u) { run[u] = 0.f; runq[u] = 0; }
-      int run_id = 0;
-      auto flush = [&]() {
-        if (run_id != 0) {                           // padding_idx row receives no gradient
-          float* dst = (float*)ep.C + (size_t)run_id * ep.ldc + nbase;
+      for (int u = 0; u < NC2; ++u) { run[u][0] = run[u][1] = 0.f; runq[u][0] = runq[u][1] = 0; }
+    };
+    const bool from_lds = i_lds && m0 + DBM - 1 < M;
+    const bool pair_ok = ((ep.Dtrue | nbase | cw0) & 1) == 0;     // every (row, even column) of this wave is an even element index
+    const bool dropping = ep.drop.thresh != 0 && !(abl & 16);
+    constexpr int RB = DET ? 2 : 4;
 #pragma unroll
-          for (int u = 0; u < NC; ++u) {
-            const int c = lane + 64 * u;
-            if (c < N && nbase + c < ep.Dtrue) {
-              if (det) { if (runq[u] != 0) nr_accum_fix(dst + c, runq[u]); }
-              else if (run[u] != 0.f) atomicAdd(dst + c, run[u]);
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+      for (int j = 0; j < HN; ++j)
+        if (wn * HN + j < NT16) *reinterpret_cast<f32x4*>(sW + (lane & 15) * SW + j * 16 + (lane >> 4) * 4) = acc[p][j];
+      // (the wave's own LDS operations execute in order: its reads below see these writes, the next pass's writes come after)
+      // token id and original row number of the pass's 16 rows: lane q holds row q's, the row loop reads them back as scalars
+      const int mb = wm * 64 + p * 16, ml = mb + (lane & 15), mg = min(m0 + ml, M - 1);
+      int idv = from_lds ? reinterpret_cast<const int*>(smem + NS * STAGE)[ml] : (compact ? ep.row_ids[mg] : ep.ids[(size_t)mg * ep.ids_stride]);
+      const int mov = !compact ? mg : (from_lds ? reinterpret_cast<const int*>(smem + NS * STAGE + 1024)[ml] : ep.row_idx[mg]);
+      if (m0 + ml >= M) idv = 0;                       // rows behind the end behave like padding rows
+      // RB rows at a time: their RB x NC2 LDS reads and dropout hashes are independent of each other and of the run logic
+      // (one row after the other, each waiting for its own id, values and hash, was a chain of latencies 64 rows long)
+#pragma unroll 1
+      for (int q0 = 0; q0 < 16; q0 += RB) {
+        float xs[RB][NC2][2];
+#pragma unroll
+        for (int t = 0; t < RB; ++t)
+#pragma unroll
+          for (int u = 0; u < NC2; ++u) {
+            const int c = 128 * u + 2 * lane;
+            float2 xv = make_float2(0.f, 0.f);
+            if (c < WC) xv = *reinterpret_cast<const float2*>(sW + (q0 + t) * SW + c);
+            xs[t][u][0] = xv.x; xs[t][u][1] = xv.y;
+          }
+        if (dropping) {
+#pragma unroll
+          for (int t = 0; t < RB; ++t) {
+            const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane(mov, q0 + t) * (uint32_t)ep.Dtrue + (uint32_t)(nbase + cw0);
+#pragma unroll
+            for (int u = 0; u < NC2; ++u) {
+              const int c = 128 * u + 2 * lane;
+              if (pair_ok) {
+                const uint32_t h = nr_pair_hash(ep.drop.key, e0 + c);
+                xs[t][u][0] = (h & 0xffffu) >= ep.drop.thresh ? xs[t][u][0] * ep.drop.scale : 0.f;
+                xs[t][u][1] = (h >> 16) >= ep.drop.thresh ? xs[t][u][1] * ep.drop.scale : 0.f;
+              } else {
+                xs[t][u][0] = nr_keep(ep.drop.key, e0 + c, ep.drop.thresh) ? xs[t][u][0] * ep.drop.scale : 0.f;
+                xs[t][u][1] = nr_keep(ep.drop.key, e0 + c + 1, ep.drop.thresh) ? xs[t][u][1] * ep.drop.scale : 0.f;
+              }
             }
           }
         }
 #pragma unroll
-        for (int u = 0; u < NC; ++u) { run[u] = 0.f; runq[u] = 0; }
-      };
-      const bool from_lds = i_lds && m0 + DBM - 1 < M;
-      for (int q = 0; q < RPW; ++q) {
-        const int rr = wid * RPW + q, mloc = pass * 64 + rr, m = m0 + mloc;
-        if (m >= M) break;
-        const int id = from_lds ? reinterpret_cast<const int*>(smem + NS * STAGE)[mloc]
-                                : (compact ? ep.row_ids[m] : ep.ids[(size_t)m * ep.ids_stride]);
-        if (id != run_id) {
-          flush();
-          run_id = id;
-        }
-        if (id == 0) continue;
-        // the dropout counter follows the ORIGINAL row
-        const int morig = !compact ? m : (from_lds ? reinterpret_cast<const int*>(smem + NS * STAGE + 1024)[mloc] : ep.row_idx[m]);
-        const uint32_t e0 = (uint32_t)morig * (uint32_t)ep.Dtrue + (uint32_t)nbase;
+        for (int t = 0; t < RB; ++t) {
+          const int id = __builtin_amdgcn_readlane(idv, q0 + t);       // wave-uniform: scalar compare and branch
+          if (id != run_id) {
+            flush();
+            run_id = id;
+          }
+          if (id != 0) {
 #pragma unroll
-        for (int u = 0; u < NC; ++u) {
-          const int c = lane + 64 * u;
-          if (c < N) {
-            float x = sC[rr * SCW + c];
-            if (ep.drop.thresh) x = nr_keep(ep.drop.key, e0 + c, ep.drop.thresh) ? x * ep.drop.scale : 0.f;
-            if (det) runq[u] += nr_to_fix(x); else run[u] += x;
+            for (int u = 0; u < NC2; ++u) {
+              if (DET) { runq[u][0] += nr_to_fix(xs[t][u][0]); runq[u][1] += nr_to_fix(xs[t][u][1]); }
+              else { run[u][0] += xs[t][u][0]; run[u][1] += xs[t][u][1]; }
+            }
           }
         }
       }
-      flush();
     }
+    flush();
+    };
+    if (det) scatter(std::true_type{}); else scatter(std::false_type{});
     return;
   }
   // epilogue: 32 rows at a time through the fp32 LDS tile (pass p = rows 32p..32p+31 = wave row wm = p>>1, tiles 2(p&1), +1)
