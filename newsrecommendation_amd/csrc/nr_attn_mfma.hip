@@ -792,7 +792,9 @@ __device__ __forceinline__ void panel_store(const bf16_t* panel, int ops, bf16_t
 // instruction issue (~420 / ~560 VALU instructions per item and wave around 4 / 14 MFMAs), and constants fold the row /
 // column predicates and the address arithmetic.
 template <bool HAS_MASK, int PT, bool SUB, bool GATHER = false, bool FULL = false, int LC = 0, int DC = 0, int HC = 0>
-__global__ __launch_bounds__(AW * 64) void fwd_kernel(AttnMArgs a) {
+// (5 waves per SIMD stated outright: left to itself the allocator parks the MFMA results in 16 AGPRs next to 80 VGPRs -- the
+//  same 96 registers of the unified file, plus 64 v_accvgpr moves per item in a kernel bound by VALU issue)
+__global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(5, 5))) void fwd_kernel(AttnMArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPR address math
   bf16_t* img0 = reinterpret_cast<bf16_t*>(smem);
@@ -1263,7 +1265,7 @@ __device__ __forceinline__ int clampL(int L, int rb) { return min(32, max(0, L -
 // LC / DC / HC: compile-time sequence length, head width and head count (0 = from the arguments), as for fwd_kernel: the
 // reference's user level (50 clicks, 20 heads of 20) gets its own instantiation
 template <bool GATHER, int LC = 0, int DC = 0, int HC = 0>
-__global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
+__global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fwd64_kernel(AttnMArgs a) {   // (no AGPR parking, see fwd_kernel)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bf16_t* base = reinterpret_cast<bf16_t*>(smem) + (size_t)wid * 7 * IMG;
@@ -1391,7 +1393,7 @@ __global__ __launch_bounds__(AW * 64) void fwd64_kernel(AttnMArgs a) {
 }
 
 template <int LC = 0, int DC = 0, int HC = 0>
-__global__ __launch_bounds__(AW * 64) void bwd64_kernel(AttnMArgs a) {
+__global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd64_kernel(AttnMArgs a) {   // (no AGPR parking, see fwd_kernel)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bf16_t* base = reinterpret_cast<bf16_t*>(smem) + (size_t)wid * 9 * IMG;
