@@ -254,6 +254,30 @@ __global__ void blend_fwd_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
+// 4 consecutive columns per thread (N % 4 == 0, 16-byte aligned rows): one 16-byte load, one mask word and one 8- / 16-byte
+// store per thread instead of four of each and a 64-bit division per element (20 -> ~10 us for the 512 x 50 history rows)
+template <typename T>
+__global__ __launch_bounds__(256) void blend_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                         const float* __restrict__ pad, T* __restrict__ out, uint32_t rows, uint32_t N4) {
+  const uint32_t total = rows * N4;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t r = i / N4, c = (i - r * N4) * 4u;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)i * 4);
+    if (mask) {
+      const float m = mask[r];
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pad + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] * m + pv[e] * (1.f - m);
+    }
+    if (sizeof(T) == 2) {
+      const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(out + (size_t)i * 4) = o;
+    } else {
+      *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = v;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void blend_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ mask,
                                                         float* __restrict__ dx, float* __restrict__ dpad, int rows,
@@ -327,12 +351,20 @@ __global__ __launch_bounds__(64) void score_ce_fwd_kernel(const float* __restric
   const int b = blockIdx.x, lane = threadIdx.x;
   const float* u = user + (size_t)b * N;
   float my = -INFINITY;  // lane j keeps score j (C <= 64)
-  for (int j = 0; j < C; ++j) {
-    const float* cr = cand + ((size_t)b * C + j) * ld_cand;
-    float p = 0.f;
-    for (int c = lane; c < N; c += 64) p = fmaf(cr[c], u[c], p);
-    p = wave_sum(p);
-    if (lane == j) my = p;
+  // 8 candidates at a time: their loads are independent (one candidate after the other was a chain of C load latencies)
+  for (int j0 = 0; j0 < C; j0 += 8) {
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = lane; c < N; c += 64) {
+      const float uc = u[c];
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (j0 + t < C) p[t] = fmaf(cand[((size_t)b * C + j0 + t) * ld_cand + c], uc, p[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float q = wave_sum(p[t]);
+      if (lane == j0 + t) my = q;
+    }
   }
   if (lane < C) score[(size_t)b * C + lane] = my;
   const float m = wave_max(my);
@@ -771,6 +803,14 @@ int nr_pad_blend_fwd(const float* x, const float* mask, const float* pad, void* 
   const size_t rows = (size_t)n * L;
   hipStream_t s = (hipStream_t)stream;
   NrProfScope ps(s, "pad_blend_fwd[n=%d,L=%d,N=%d]", n, L, N);
+  if (N % 4 == 0 && rows * (size_t)(N / 4) < (1ull << 31) && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)pad) & 15) == 0) {
+    const uint32_t N4 = (uint32_t)(N / 4);
+    const dim3 grid(grid_for(rows * N4));
+    if (dtype == NR_BF16) hipLaunchKernelGGL(blend_fwd4_kernel<bf16_t>, grid, dim3(256), 0, s, x, mask, pad, (bf16_t*)out, (uint32_t)rows, N4);
+    else hipLaunchKernelGGL(blend_fwd4_kernel<float>, grid, dim3(256), 0, s, x, mask, pad, (float*)out, (uint32_t)rows, N4);
+    NR_CHECK_LAUNCH();
+    return NR_OK;
+  }
   if (dtype == NR_BF16)
     hipLaunchKernelGGL(blend_fwd_kernel<bf16_t>, dim3(grid_for(rows * N)), dim3(256), 0, s, x, mask, pad, (bf16_t*)out, rows, N);
   else
