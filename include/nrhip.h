@@ -361,6 +361,13 @@ int nr_assemble_batch(const int32_t* news_combined, int n_rows, int F, const int
                       const int32_t* neg_idx, const int64_t* label, int B, int H, int K, int32_t* history, int32_t* candidate,
                       int32_t* bad, nr_stream_t stream);
 
+/* One encoder batch, Model.forward's `torch.cat([candidate titles, history titles])` (the reference encodes the two in two
+ * passes, src/model/NRMS.py:87,90 / src/model/NAML.py forward; one pass here) plus the "is this title's vector used at all"
+ * flags of the rows: out [rows_a + rows_b, F] = [a ; b], flags [rows_a + rows_b] = [1 .. 1 ; mask_b != 0] (flags and mask_b
+ * optional; a NULL mask_b flags every row).                                                                          */
+int nr_stack_rows(const int32_t* a, int rows_a, const int32_t* b, int rows_b, int F, const float* mask_b, int32_t* out,
+                  int32_t* flags, nr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * f2  on-device ranking metrics -- src/metrics.py:5-23 (dcg/ndcg/mrr), sklearn roc_auc_score (src/metrics.py:1),
  * accumulated as src/main.py:249-263 does.  Impression i owns score / label entries [offsets[i], offsets[i+1]).
@@ -385,6 +392,18 @@ int nr_eval_metrics(const float* score, const int32_t* label, const int32_t* off
  * step >= 1 is the 1-based update count.  Buffers 16-byte aligned.                                               */
 int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2, float eps,
                  int step, float grad_scale, int zero_grad, nr_stream_t stream);
+/* The same update, plus the packed bf16 GEMM operands of parameter matrices that live in the bucket (what nr_cast_pad would
+ * make of the new values -- bit-identical -- written in the same pass).  Job j: the matrix at elements [first, first + count)
+ * of the bucket, `cols` columns per row (a multiple of 4, as is `first`), goes to dst [count / cols, ld_dst] bf16; padding
+ * columns of dst are not touched (nr_cast_pad zeroed them when the operand was first made).  At most NR_ADAM_PACK_MAX jobs. */
+#define NR_ADAM_PACK_MAX 4
+typedef struct {
+  size_t first, count;
+  int cols, ld_dst;
+  void* dst;
+} nr_pack_job;
+int nr_adam_step_packed(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2, float eps,
+                        int step, float grad_scale, int zero_grad, const nr_pack_job* jobs, int n_jobs, nr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Per-kernel timing (measurement only).  While enabled, every kernel launch inside the library is

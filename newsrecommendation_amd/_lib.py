@@ -49,6 +49,13 @@ class CastJob(C.Structure):
                 ("ld_dst", C.c_int), ("transpose", C.c_int)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("first", C.c_size_t), ("count", C.c_size_t), ("cols", C.c_int), ("ld_dst", C.c_int), ("dst", C.c_void_p)]
+
+
+ADAM_PACK_MAX = 4
+
+
 class PoolDesc(C.Structure):
     _fields_ = [("n", C.c_int), ("L", C.c_int), ("N", C.c_int), ("q", C.c_int), ("dtype", C.c_int), ("x", C.c_void_p),
                 ("mask", C.c_void_p), ("w1", C.c_void_p), ("ldw1", C.c_int), ("b1", C.c_void_p), ("w2", C.c_void_p),
@@ -81,9 +88,11 @@ SIGNATURES = {
     "nr_sdpa_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u32, _vp],
     "nr_sdpa_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _u32, _vp],
     "nr_assemble_batch": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "nr_stack_rows": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "nr_eval_metrics_workspace_bytes": [_i],
     "nr_eval_metrics": [_vp, _vp, _vp, _i, _i, _vp, C.c_size_t, _vp, _vp],
     "nr_adam_step": [_vp, _vp, _vp, _vp, C.c_size_t, _f, _f, _f, _f, _i, _f, _i, _vp],
+    "nr_adam_step_packed": [_vp, _vp, _vp, _vp, C.c_size_t, _f, _f, _f, _f, _i, _f, _i, _vp, _i, _vp],
     "nr_check_ids": [_vp, _i, _i, _i, _vp, _vp],
     "nr_check_labels": [_vp, _i, _i, _vp, _vp],
     "nr_cast_pad": [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp],

@@ -161,8 +161,18 @@ __device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, co
   if (c.zero_grad) g = 0.f;
 }
 
+// Packed (bf16, row-padded) copies of parameter matrices that live in the bucket: written in the same pass as the update
+// itself, bit-identical to what nr_cast_pad makes of the new values (the separate re-pack of a 30 000 x 300 word table was
+// 15 us per step).  first / count in elements, both multiples of 4, cols a multiple of 4: a thread's 4 values share a row.
+struct AdamPacks {
+  int n;
+  unsigned long long first[NR_ADAM_PACK_MAX], count[NR_ADAM_PACK_MAX];
+  int cols[NR_ADAM_PACK_MAX], ld[NR_ADAM_PACK_MAX];
+  bf16_t* dst[NR_ADAM_PACK_MAX];
+};
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                    size_t n, AdamCfg c) {
+                                                    size_t n, AdamCfg c, AdamPacks pk) {
   const size_t n4 = n / 4;
   f32x4* p4 = reinterpret_cast<f32x4*>(p);
   f32x4* g4 = reinterpret_cast<f32x4*>(g);
@@ -175,6 +185,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 #pragma unroll
     for (int e = 0; e < 4; ++e) adam1(pp[e], gg[e], mm[e], ww[e], c);
     p4[i] = (f32x4){pp[0], pp[1], pp[2], pp[3]};
+    for (int j = 0; j < pk.n; ++j) {
+      const unsigned long long e = (unsigned long long)i * 4 - pk.first[j];       // (wraps to a huge value in front of the range)
+      if (e < pk.count[j]) {
+        const uint32_t r = (uint32_t)e / (uint32_t)pk.cols[j], col = (uint32_t)e - r * (uint32_t)pk.cols[j];
+        const bf16x4 o = {(bf16_t)pp[0], (bf16_t)pp[1], (bf16_t)pp[2], (bf16_t)pp[3]};
+        *reinterpret_cast<bf16x4*>(pk.dst[j] + (size_t)r * pk.ld[j] + col) = o;
+      }
+    }
     m4[i] = (f32x4){mm[0], mm[1], mm[2], mm[3]};
     v4[i] = (f32x4){ww[0], ww[1], ww[2], ww[3]};
     if (c.zero_grad) g4[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -183,9 +201,39 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
   if (tail < n) adam1(p[tail], g[tail], m[tail], v[tail], c);
 }
 
+
+
+// ------------------------------------------------------------------------------------------ one encoder batch
+// out = [a ; b] (rows of F int32 ids), flags = [1 ... 1 ; mask_b != 0]: what Model.forward hands the news encoder -- the
+// candidate titles followed by the history titles and the "is this title's vector used at all" flags -- in one launch
+// (torch needed a fill, two concatenations, a compare and a cast: five launches of ~5 us each).
+__global__ __launch_bounds__(256) void stack_rows_kernel(const int32_t* __restrict__ a, long na, const int32_t* __restrict__ b, long nb, int F,
+                                                         const float* __restrict__ mask_b, int32_t* __restrict__ out,
+                                                         int32_t* __restrict__ flags) {
+  const long ea = na * F, total = (na + nb) * F;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) out[e] = e < ea ? a[e] : b[e - ea];
+  if (flags != nullptr)
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < na + nb; r += (long)gridDim.x * 256)
+      flags[r] = r < na ? 1 : (mask_b == nullptr || mask_b[r - na] != 0.f ? 1 : 0);
+}
+
 }  // namespace
 
 extern "C" {
+
+int nr_stack_rows(const int32_t* a, int rows_a, const int32_t* b, int rows_b, int F, const float* mask_b, int32_t* out, int32_t* flags,
+                  nr_stream_t stream) {
+  NR_CHECK_ARG(rows_a >= 0 && rows_b >= 0 && F >= 1, "stack_rows: bad sizes %d + %d rows of %d", rows_a, rows_b, F);
+  if (rows_a + rows_b == 0) return NR_OK;
+  NR_CHECK_ARG((rows_a == 0 || a) && (rows_b == 0 || b) && out, "stack_rows: null pointer");
+  NR_DEVICE_GUARD(stream, out);
+  const long total = ((long)rows_a + rows_b) * F, blocks = (total + 255) / 256;
+  NrProfScope ps((hipStream_t)stream, "stack_rows[%d+%d,F=%d]", rows_a, rows_b, F);
+  hipLaunchKernelGGL(stack_rows_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream, a, (long)rows_a, b,
+                     (long)rows_b, F, mask_b, out, flags);
+  NR_CHECK_LAUNCH();
+  return NR_OK;
+}
 
 int nr_assemble_batch(const int32_t* news_combined, int n_rows, int F, const int32_t* hist_idx, const int32_t* pos_idx,
                       const int32_t* neg_idx, const int64_t* label, int B, int H, int K, int32_t* history, int32_t* candidate,
@@ -234,6 +282,23 @@ int nr_eval_metrics(const float* score, const int32_t* label, const int32_t* off
 
 int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2, float eps,
                  int step, float grad_scale, int zero_grad, nr_stream_t stream) {
+  return nr_adam_step_packed(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale, zero_grad, nullptr, 0, stream);
+}
+
+int nr_adam_step_packed(float* param, float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr, float beta1, float beta2, float eps,
+                        int step, float grad_scale, int zero_grad, const nr_pack_job* jobs, int n_jobs, nr_stream_t stream) {
+  NR_CHECK_ARG(n_jobs >= 0 && n_jobs <= NR_ADAM_PACK_MAX && (n_jobs == 0 || jobs != nullptr), "adam_step: %d pack jobs (at most %d)", n_jobs,
+               NR_ADAM_PACK_MAX);
+  AdamPacks pk;
+  pk.n = n_jobs;
+  for (int j = 0; j < n_jobs; ++j) {
+    const nr_pack_job& q = jobs[j];
+    NR_CHECK_ARG(q.dst != nullptr && q.cols >= 4 && q.cols % 4 == 0 && q.ld_dst >= q.cols && q.ld_dst % 4 == 0 && q.first % 4 == 0 &&
+                     q.count % (size_t)q.cols == 0 && q.count < (1ull << 32) && q.first + q.count <= n && (((uintptr_t)q.dst) & 7) == 0,
+                 "adam_step: pack job %d (first %zu, count %zu, cols %d, ld %d) must cover whole rows of a multiple of 4 columns inside the bucket",
+                 j, q.first, q.count, q.cols, q.ld_dst);
+    pk.first[j] = q.first; pk.count[j] = q.count; pk.cols[j] = q.cols; pk.ld[j] = q.ld_dst; pk.dst[j] = reinterpret_cast<bf16_t*>(q.dst);
+  }
   NR_CHECK_ARG(step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "adam_step: bad hyper-parameters");
   if (n == 0) return NR_OK;
   NR_CHECK_ARG(param && grad && exp_avg && exp_avg_sq, "adam_step: null pointer");
@@ -248,7 +313,7 @@ int nr_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, s
   const size_t blocks = (n4 + 255) / 256;
   NrProfScope ps((hipStream_t)stream, "adam_step[n=%zu]", n);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
-                     n, c);
+                     n, c, pk);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }

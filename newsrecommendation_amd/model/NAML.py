@@ -196,11 +196,15 @@ class Model(torch.nn.Module):
         a = self.args
         F = history.shape[-1]
         B, C = candidate.shape[0], 1 + a.npratio
-        needed = None                                  # masked history slots reach the loss through a factor 0 (NAML.py:92-96)
-        if not getattr(a, "encode_masked_slots", False):
-            needed = torch.cat([history_mask.new_ones(B * C), history_mask.reshape(-1)])
-        vecs = self.news_encoder(torch.cat([candidate.reshape(-1, F), history.reshape(-1, F)], dim=0), needed=needed)
-        cand_flat, hist_flat = vecs.split([B * C, vecs.shape[0] - B * C], dim=0)     # one cat in backward, no zero fills
+        # masked history slots reach the loss through a factor 0 (NAML.py:92-96): the encoder is told (flags), one launch
+        want = not getattr(a, "encode_masked_slots", False)
+        if candidate.is_cuda:
+            ids, needed = ops.stack_rows(candidate.reshape(-1, F), history.reshape(-1, F), history_mask, flags=want)
+        else:
+            ids = torch.cat([candidate.reshape(-1, F), history.reshape(-1, F)], dim=0)
+            needed = torch.cat([history_mask.new_ones(B * C), history_mask.reshape(-1)]) if want else None
+        vecs = self.news_encoder(ids, needed=needed)
+        cand_flat, hist_flat = ops.split_rows(vecs, B * C)             # its backward is not even a concatenation (see ops)
         cand_vecs = cand_flat.reshape(B, C, a.news_dim)
         hist_vecs = hist_flat.reshape(B, a.user_log_length, a.news_dim)
         user_vec = self.user_encoder(hist_vecs, history_mask)

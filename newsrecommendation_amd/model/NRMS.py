@@ -113,12 +113,15 @@ class Model(torch.nn.Module):
             # History slots with mask 0 reach the loss through a factor 0 only (pad-doc blend NRMS.py:59-60, or masked out of
             # the user-level attention and pooling, model_utils.py:28,51): the encoder is told, and returns zeros for them
             # without computing them.  Same loss, scores and gradients; `args.encode_masked_slots=True` switches it off.
-            needed = None
-            if not getattr(a, "encode_masked_slots", False):
-                needed = torch.cat([history_mask.new_ones(B * C), history_mask.reshape(-1)])
-            vecs = self.news_encoder(torch.cat([cand, hist], dim=0), needed=needed)
+            if cand.is_cuda:
+                ids, needed = ops.stack_rows(cand, hist, history_mask, flags=not getattr(a, "encode_masked_slots", False))
+            else:
+                ids, needed = torch.cat([cand, hist], dim=0), None
+                if not getattr(a, "encode_masked_slots", False):
+                    needed = torch.cat([history_mask.new_ones(B * C), history_mask.reshape(-1)])
+            vecs = self.news_encoder(ids, needed=needed)
         # split, not two slices: its backward is one concatenation instead of two zero-filled full-size buffers and an add
-        cand_flat, hist_flat = vecs.split([B * C, vecs.shape[0] - B * C], dim=0)
+        cand_flat, hist_flat = ops.split_rows(vecs, B * C) if not compact else vecs.split([B * C, vecs.shape[0] - B * C], dim=0)
         if compact:
             hist_flat = vecs.new_zeros(hist.shape[0], a.news_dim).index_copy(0, live, hist_flat)
         cand_vecs = cand_flat.reshape(B, C, a.news_dim)

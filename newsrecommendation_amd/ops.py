@@ -290,6 +290,13 @@ class _TableCache:
         else:
             self._drop(id(weight))
 
+    def current(self, weight):
+        """[(code, row_cols, packed copy)] of the up-to-date entries of `weight` (what an optimizer that rewrites the master
+        behind autograd's back can refresh in place instead of invalidating, parallel.FlatBucket.adam_step)."""
+        w = weight.detach()
+        sig = (weight._version, w.data_ptr(), tuple(w.shape))
+        return [(k[1], k[2], e[1]) for k, e in self._c.items() if k[0] == id(weight) and e[0] == sig and e[2]() is weight]
+
     def get(self, weight: torch.Tensor, code: int, row_cols: Optional[int] = None) -> torch.Tensor:
         w = weight.detach()
         cols = row_cols or w.shape[1]
@@ -494,6 +501,8 @@ def needed_flags(needed):
     """[n] int32 flags (1 = the caller uses this sequence's output) from a bool / float / int tensor, or None."""
     if needed is None:
         return None
+    if getattr(needed, "_nr_flags01", False):          # stack_rows made them: int32 0 / 1, contiguous
+        return needed
     return (needed.reshape(-1) != 0).to(torch.int32).contiguous()
 
 
@@ -667,6 +676,48 @@ def additive_pool(x, w1, b1, w2, b2, code: int, mask=None, needed=None, lazy_dx=
 
 
 # ------------------------------------------------------------------------------------------ pad blend / cast
+# Row split whose backward is not a copy.  `torch.split` of the encoder output [candidates ; history] gets its gradient as a
+# concatenation of the two consumers' gradients (45 MB written and read again per step at B = 512).  split_rows allocates that
+# gradient buffer up front and registers its two halves under the addresses of the two outputs; a libnrhip backward that
+# produces the gradient of exactly such a tensor (the pad-doc blend of the history rows, the scorer for the candidates) writes
+# into the registered half, and the split's backward recognises the two halves and returns the buffer as it stands.  Anything
+# else -- another consumer, an accumulation, a copy in between -- arrives in some other tensor and is concatenated as before.
+_grad_out = {}
+
+
+def _take_grad_out(x):
+    if not _grad_out or not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous():
+        return None
+    return _grad_out.pop((x.data_ptr(), x.numel()), None)
+
+
+class SplitRowsFunction(Function):
+    @staticmethod
+    def forward(ctx, x, n_a):
+        ctx.n_a, ctx.arena = int(n_a), None
+        a, b = x[:n_a], x[n_a:]
+        _grad_out.clear()
+        if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2 and 0 < n_a < x.shape[0]:
+            ctx.arena = torch.empty_like(x)
+            _grad_out[(a.data_ptr(), a.numel())] = ctx.arena[:n_a]
+            _grad_out[(b.data_ptr(), b.numel())] = ctx.arena[n_a:]
+        return a, b
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        arena, n_a = ctx.arena, ctx.n_a
+        if (arena is not None and ga is not None and gb is not None and ga.dtype == gb.dtype == torch.float32 and ga.is_contiguous()
+                and gb.is_contiguous() and ga.data_ptr() == arena.data_ptr() and gb.data_ptr() == arena[n_a:].data_ptr()
+                and ga.numel() == arena[:n_a].numel() and gb.numel() == arena[n_a:].numel()):
+            return arena, None
+        return torch.cat([ga, gb], dim=0), None
+
+
+def split_rows(x, n_a: int):
+    """x[:n_a], x[n_a:] -- see above."""
+    return SplitRowsFunction.apply(x, n_a)
+
+
 class BlendFunction(Function):
     """K6: x*m + pad_doc*(1-m) (src/model/NRMS.py:59-60, src/model/NAML.py:94-95), emitted in the
     compute dtype.  mask=None is a plain fp32 -> compute-dtype cast with an fp32 gradient."""
@@ -682,6 +733,7 @@ class BlendFunction(Function):
         check(_lib.lib().nr_pad_blend_fwd(ptr(x), ptr(mask_c), ptr(pad_c), ptr(out), n, L, N, code, _stream()), "nr_pad_blend_fwd")
         ctx.code, ctx.dims, ctx.pad_shape = code, (n, L, N), (tuple(pad.shape) if pad is not None else None)
         ctx.pad_target = grad_target(pad)
+        ctx.dx_out = _take_grad_out(x)                   # split_rows: write dx where the producer's gradient is assembled
         ctx.save_for_backward(mask_c)
         return out
 
@@ -693,7 +745,7 @@ class BlendFunction(Function):
         dout = dout.contiguous()
         if dout.dtype != torch_dtype(ctx.code):
             dout = dout.to(torch_dtype(ctx.code))
-        dx = torch.empty(n, L, N, dtype=torch.float32, device=dout.device)
+        dx = ctx.dx_out.view(n, L, N) if ctx.dx_out is not None else torch.empty(n, L, N, dtype=torch.float32, device=dout.device)
         direct = ctx.pad_target is not None and mask_c is not None
         dpad = ctx.pad_target if direct else (torch.zeros(N, dtype=torch.float32, device=dout.device) if mask_c is not None else None)
         check(_lib.lib().nr_pad_blend_bwd(ptr(dout), ptr(mask_c), ptr(dx), ptr(dpad), n, L, N, ctx.code, _stream()), "nr_pad_blend_bwd")
@@ -729,6 +781,8 @@ class ScoreCEFunction(Function):
         check(_lib.lib().nr_score_ce_fwd(ptr(cand), N, ptr(user), ptr(label), ptr(score), ptr(loss), ptr(lossvec), B, Cn, N,
                                          _stream()), "nr_score_ce_fwd")
         ctx.save_for_backward(cand, user, label, score)
+        ctx.dcand_out = _take_grad_out(cand)
+        ctx.set_materialize_grads(False)                 # an unused `score` output then costs no zero fill in the backward
         return loss, score
 
     @staticmethod
@@ -738,7 +792,7 @@ class ScoreCEFunction(Function):
         B, Cn, N = cand.shape
         gl = gloss.contiguous().float() if gloss is not None else None
         gs = gscore.contiguous().float() if gscore is not None else None
-        dcand = torch.empty_like(cand)
+        dcand = ctx.dcand_out.view_as(cand) if ctx.dcand_out is not None else torch.empty_like(cand)
         duser = torch.empty_like(user)
         check(_lib.lib().nr_score_ce_bwd(ptr(cand), N, ptr(user), ptr(label), ptr(score), ptr(gl), ptr(gs), ptr(dcand), N,
                                          ptr(duser), B, Cn, N, _stream()), "nr_score_ce_bwd")
@@ -909,6 +963,29 @@ def score_eval(news_vecs, cand_ids, imp_of, user_vecs) -> torch.Tensor:
     check(_lib.lib().nr_score_eval(ptr(news_vecs), N, ptr(cand_ids), ptr(imp_of), ptr(user_vecs), N, ptr(out),
                                    cand_ids.numel(), N, _stream()), "nr_score_eval")
     return out
+
+
+def stack_rows(a, b, mask_b=None, flags=True):
+    """[a ; b] of two int32 id matrices with the same row width (candidate titles, then history titles) and, if asked, the int32
+    "needed" flags [1 .. 1 ; mask_b != 0] of the stacked rows -- one launch (nr_stack_rows)."""
+    _need_gpu(a, b, mask_b)
+    a2, b2 = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+    if a2.shape[1] != b2.shape[1]:
+        raise RuntimeError(f"stack_rows: row widths differ ({a2.shape[1]} vs {b2.shape[1]})")
+    a2, b2 = (t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous() for t in (a2, b2))
+    m = None
+    if mask_b is not None:
+        m = mask_b.reshape(-1)
+        if m.dtype != torch.float32 or not m.is_contiguous():
+            m = m.float().contiguous()
+        if m.numel() != b2.shape[0]:
+            raise RuntimeError(f"stack_rows: {m.numel()} mask entries for {b2.shape[0]} rows")
+    out = torch.empty(a2.shape[0] + b2.shape[0], a2.shape[1], dtype=torch.int32, device=a2.device)
+    fl = torch.empty(out.shape[0], dtype=torch.int32, device=out.device) if flags else None
+    check(_lib.lib().nr_stack_rows(ptr(a2), a2.shape[0], ptr(b2), b2.shape[0], a2.shape[1], ptr(m), ptr(out), ptr(fl), _stream()), "nr_stack_rows")
+    if fl is not None:
+        fl._nr_flags01 = True
+    return out, fl
 
 
 def assemble_batch(news_combined, hist_idx, pos_idx, neg_idx, label):

@@ -160,13 +160,39 @@ class FlatBucket:
             dist.broadcast(self.param, src=0, group=group)
         self._params_changed()
 
-    def _params_changed(self):
+    def _params_changed(self, repacked=()):
         """The kernels wrote the parameters behind autograd's back (no version bump): packed compute-dtype copies of the
-        bucket's OWN tables must be rebuilt.  Frozen tables (e.g. NAML's 2.3 GB title table) are not touched."""
+        bucket's OWN tables must be rebuilt -- except those the Adam kernel rewrote itself (`repacked`: parameter ids).
+        Frozen tables (e.g. NAML's 2.3 GB title table) are not touched."""
         from . import ops
         for p in self.params:
-            ops.table_cache.invalidate(p)
+            if id(p) not in repacked:
+                ops.table_cache.invalidate(p)
         ops.bump_param_epoch()
+
+    def _pack_jobs(self):
+        """The bucket's embedding tables that have an up-to-date packed bf16 copy (ops.table_cache): nr_adam_step_packed writes
+        the new values into that copy in the same pass, so the next forward finds it current (no nr_cast_pad of the table)."""
+        from . import _lib, ops
+        jobs, ids = [], set()
+        for p in self.params:
+            ents = ops.table_cache.current(p)
+            if not ents or len(jobs) + len(ents) > _lib.ADAM_PACK_MAX:
+                continue
+            first = (p.data_ptr() - self.param.data_ptr()) // 4
+            mine = []
+            for code, cols, packed in ents:
+                ok = (code == _lib.NR_BF16 and cols % 4 == 0 and first % 4 == 0 and p.numel() % cols == 0 and p.numel() < 2 ** 32
+                      and packed.dtype == torch.bfloat16 and packed.is_contiguous() and packed.dim() == 2
+                      and packed.shape[0] == p.numel() // cols and packed.shape[1] >= cols and packed.shape[1] % 4 == 0)
+                if not ok:
+                    mine = None
+                    break
+                mine.append(_lib.PackJob(first, p.numel(), cols, packed.shape[1], packed.data_ptr()))
+            if mine:
+                jobs += mine
+                ids.add(id(p))
+        return jobs, ids
 
     def _versions(self):
         return tuple(p._version for p in self.params)
@@ -208,11 +234,14 @@ class FlatBucket:
                                "(libnrhip has no CPU fallback)")
         from . import _lib
         self.t += 1
-        _lib.check(_lib.lib().nr_adam_step(self.param.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
-                                           self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps,
-                                           self.t, 1.0 / self.world, int(zero_grad), torch.cuda.current_stream().cuda_stream),
-                   "nr_adam_step")
-        self._params_changed()
+        jobs, repacked = self._pack_jobs()
+        arr = (_lib.PackJob * len(jobs))(*jobs) if jobs else None
+        _lib.check(_lib.lib().nr_adam_step_packed(self.param.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                  self.exp_avg_sq.data_ptr(), self.numel, self.lr, self.betas[0], self.betas[1], self.eps,
+                                                  self.t, 1.0 / self.world, int(zero_grad), arr, len(jobs),
+                                                  torch.cuda.current_stream().cuda_stream),
+                   "nr_adam_step_packed")
+        self._params_changed(repacked)
 
     def step(self):
         self.allreduce()
