@@ -617,6 +617,7 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   NR_CHECK_ARG(qkv != nullptr, "mhsa_fwd: the unfused path needs the qkv buffer (see nr_mhsa_fwd_fused)");
   EpiArgs ep = store_epi(qkv, 3 * N, d->dtype, d->b_qkv, 0);
   const uint32_t* tmask = nullptr;
+  bool seq_hdr_zeroed = false;
   if (d->x_rows != nullptr && d->src_kind == NR_SRC_GATHER) {
     // gather + dropout once into x_rows (kept for the backward), then a plain dense projection GEMM
     NR_CHECK_ARG(d->ld_rows >= Kp && d->ld_rows % nr_chunk(d->dtype) == 0, "mhsa_fwd: ld_rows=%d must cover %d", d->ld_rows, Kp);
@@ -625,8 +626,11 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
     // Padding tokens (id 0) gather the zero row of the table: their projection is the bias.  Project the live rows
     // only (compacted on the device) and write the bias into the others.  If table row 0 is not zero, the
     // compaction keeps every row and nothing changes.
-    if (compacting && (rc = nr_launch_compact_rows_fwd(d->ids, M, d->n, d->L, d->x, d->d_model, d->row_ws, s, cstore ? d->row_ws + W.pos : nullptr)))
+    // (the compaction kernel also clears the counters of the "needed" list built further down: one memset less in the chain)
+    if (compacting && (rc = nr_launch_compact_rows_fwd(d->ids, M, d->n, d->L, d->x, d->d_model, d->row_ws, s, cstore ? d->row_ws + W.pos : nullptr,
+                                                       d->row_ws + W.seq)))
       return rc;
+    seq_hdr_zeroed = compacting;
     if (cstore) {
       NR_CHECK_ARG(nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, y), "mhsa_fwd: qkv / y must be 8-byte aligned");
       if ((rc = nr_launch_gather_live_rows(d->dtype, A, d->x_rows, d->ld_rows, M, Kp, d->row_ws, d->row_ws + W.live_idx, d->row_ws + W.live_ids, s)))
@@ -665,7 +669,7 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
   if (d->seq_needed != nullptr && tmask != nullptr && ((size_t)d->L * N * nr_elt_size(d->dtype)) % 16 == 0 && (((uintptr_t)y) & 15) == 0) {
     int32_t* lw = d->row_ws + W.seq;
     if ((rc = nr_launch_needed_list(d->seq_needed, d->n, lw, y, (size_t)d->L * N * nr_elt_size(d->dtype), s,
-                                    d->y_far_unwritten ? 32 / d->L + 2 : -1)))
+                                    d->y_far_unwritten ? 32 / d->L + 2 : -1, seq_hdr_zeroed)))
       return rc;
     fwd_list = lw;
   }
@@ -708,24 +712,25 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
     NR_CHECK_ARG(dtable != nullptr && dx == nullptr && w_qkv_t != nullptr && ldwt >= 3 * N, "mhsa_bwd: gather source takes dtable (and w_qkv_t [d_model, >=3N])");
     int32_t* ws = d->row_ws;
     if (ph_main) {
-      int32_t* slab_ws = ws + W.slab;                  // n sequence flags: which sequences got a non-zero upstream gradient
-      if (d->seq_nz != nullptr) {
-        NR_CHECK_HIP(hipMemcpyAsync(slab_ws, d->seq_nz, (size_t)d->n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-      } else if ((rc = nr_launch_title_flags(dy, d->n, d->L, N, slab_ws, s))) {
-        return rc;
+      // n sequence flags: which sequences got a non-zero upstream gradient (the caller's, read in place, or made here)
+      const int32_t* slab_ws = d->seq_nz;
+      if (slab_ws == nullptr) {
+        if ((rc = nr_launch_title_flags(dy, d->n, d->L, N, ws + W.slab, s))) return rc;
+        slab_ws = ws + W.slab;
       }
+      // rows count .. roundup32(count) of dqkv: the weight-gradient GEMM contracts whole 32-row slabs (x_c is zero there);
+      // the same launch clears the counters of the sequence list and the histogram of the id sort that follow
+      int32_t* seq_ws = ws + W.seq;
+      if ((rc = nr_launch_zero_tail_rows(dqkv, 3 * N, ws, M, s, seq_ws, 4, ws + W.hist, d->table_rows))) return rc;
       // the walk leaves out the all-padding sequences with a zero gradient (nothing to store, nothing to add to db); slab
       // distances do not matter any more -- no slab is contracted -- so the list kernel runs with a zero reach
-      int32_t* seq_ws = ws + W.seq;
-      if ((rc = nr_launch_seq_list(slab_ws, tmask, d->n, d->L, seq_ws, s, /*reach=*/0))) return rc;
-      // rows count .. roundup32(count) of dqkv: the weight-gradient GEMM contracts whole 32-row slabs (x_c is zero there)
-      if ((rc = nr_launch_zero_tail_rows(dqkv, 3 * N, ws, M, s))) return rc;
+      if ((rc = nr_launch_seq_list(slab_ws, tmask, d->n, d->L, seq_ws, s, /*reach=*/0, /*zeroed=*/true))) return rc;
       if ((rc = nr_launch_attn_bwd_compact(qkv, d->mask, dy, dqkv, d->n, d->L, d->heads, d->d_head, nr_make_drop(d->p_out, d->seed_out), s, tmask,
                                            d->b_qkv, seq_ws + 4, seq_ws, ws + W.pos, ws + W.dump, db_qkv, d->dy_far_unwritten ? slab_ws : nullptr)))
         return rc;
       // table gradient: rows in token-id order, A rows through their live-list positions
       if ((rc = nr_launch_sort_rows_by_id(ws, ws + W.live_idx, ws + W.live_ids, M, d->table_rows, ws + W.hist, ws + W.sort_idx, ws + W.sort_ids, s,
-                                          ws + W.sort_k)))
+                                          ws + W.sort_k, /*hist_zeroed=*/true)))
         return rc;
       EpiArgs ep = store_epi(dtable, d->d_model, NR_F32, nullptr, 0);
       ep.ids = d->ids; ep.ids_stride = 1; ep.Dtrue = d->d_model; ep.drop = nr_make_drop(d->p_in, d->seed_in);

@@ -75,12 +75,12 @@ int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* w
 // hist int32 [table_rows + 8] scratch).  Order inside a group is arbitrary.
 // k_out (optional): position of each sorted row in the unsorted live list
 int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const int32_t* ids, int Mmax, int table_rows, int32_t* hist,
-                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream, int32_t* k_out = nullptr);
+                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream, int32_t* k_out = nullptr, bool hist_zeroed = false);
 // forward flavour: ws int32 [3*M + n + 4] (adds ws[1] = dead count, ws[2] = "table row 0 is not zero", ws[4+2M ..] dead rows,
 // ws[4+3M ..] per-sequence live-token bit masks when L <= 32)
 // posmap (optional [M]): position of every row in the live list (-1: dead)
 int nr_launch_compact_rows_fwd(const int32_t* ids, int M, int n, int L, const void* table_row0, int cols, int32_t* ws,
-                               hipStream_t stream, int32_t* posmap = nullptr);
+                               hipStream_t stream, int32_t* posmap = nullptr, int32_t* zero4 = nullptr);   // zero4: 4 more counters to clear
 // tmask (optional, with L): rows of sequences whose live-token mask is 0 are skipped (the attention kernels cover them)
 int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_t* rows, const int32_t* count, int max_rows,
                         const uint32_t* tmask, int L, hipStream_t stream);
@@ -89,10 +89,14 @@ int nr_launch_title_flags(const void* dy, int n, int L, int N, int32_t* title_nz
 int nr_launch_row_flags_f32(const float* g, int ld, int N, int n, int32_t* nz, hipStream_t stream);
 int nr_launch_live_slabs(int32_t* ws, int n, int L, hipStream_t stream);
 // reach >= 0: the y rows of an unneeded sequence are zero-filled only when a needed one lies within `reach` sequences
-int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream, int reach = -1);
+int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream, int reach = -1,
+                          bool zeroed = false);   // zeroed: out[0..4) was cleared by an earlier kernel of the call
 // reach: an all-padding sequence is left out when its own and `reach` neighbours' gradients are zero (-1: 32 / L + 2, the span of a slab)
-int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream, int reach = -1);
-int nr_launch_zero_tail_rows(void* buf, int ld, const int32_t* count, int Mmax, hipStream_t stream);
+int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream, int reach = -1,
+                       bool zeroed = false);
+// za [na] / zb [nb] (optional int32 regions): cleared by the same launch
+int nr_launch_zero_tail_rows(void* buf, int ld, const int32_t* count, int Mmax, hipStream_t stream, int32_t* za = nullptr, int na = 0,
+                             int32_t* zb = nullptr, int nb = 0);
 // scratch (optional, nr_gemm_tn_scratch_floats(M, N, K) floats, 16-byte aligned): the splits store their partial tiles there
 // and a reduce pass adds them up in order, instead of every split adding its tile into dW with fp32 atomics
 int nr_launch_gemm_tn_slabs(const void* dC, int ldc, const void* X, int ldx, float* dW, int ldw, float* db, int M, int N, int K,

@@ -3169,7 +3169,8 @@ __global__ __launch_bounds__(256) void bias_rows_kernel(bf16_t* __restrict__ C, 
 // from the flags it has in LDS anyway (both used to be launches of their own).
 __global__ __launch_bounds__(256) void compact_rows_fwd_kernel(const int32_t* __restrict__ ids, int M, int n, int L,
                                                                const bf16_t* __restrict__ row0, int cols, int32_t* __restrict__ ws,
-                                                               int32_t* __restrict__ posmap, uint32_t* __restrict__ tmask, int rows_per_wg) {
+                                                               int32_t* __restrict__ posmap, uint32_t* __restrict__ tmask, int rows_per_wg,
+                                                               int32_t* __restrict__ zero4) {
   constexpr int RPT = 16;
   __shared__ int wave_cnt[RPT][4];
   __shared__ int base, dbase;
@@ -3179,6 +3180,7 @@ __global__ __launch_bounds__(256) void compact_rows_fwd_kernel(const int32_t* __
   for (int c = tid; c < cols; c += 256) nz |= (float)row0[c] != 0.f;
   const bool keep_all = __syncthreads_or(nz) != 0;
   if (blockIdx.x == 0 && tid == 0) ws[2] = keep_all ? 1 : 0;
+  if (zero4 != nullptr && blockIdx.x == 0 && tid < 4) zero4[tid] = 0;       // the counters of a list a LATER kernel of the call builds
   const int r0 = blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
   int id[RPT];
   uint64_t bal[RPT];
@@ -3343,10 +3345,10 @@ __global__ __launch_bounds__(256) void id_scatter_kernel(const int32_t* __restri
 }  // namespace
 
 int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const int32_t* ids, int Mmax, int table_rows, int32_t* hist,
-                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream, int32_t* k_out) {
+                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream, int32_t* k_out, bool hist_zeroed) {
   NR_CHECK_ARG(count && rows && ids && hist && rows_out && ids_out && Mmax > 0 && table_rows > 0, "sort_rows_by_id: bad arguments");
   NrProfScope ps(stream, "sort_rows_by_id[Mmax=%d,V=%d]", Mmax, table_rows);
-  NR_CHECK_HIP(hipMemsetAsync(hist, 0, (size_t)table_rows * sizeof(int32_t), stream));
+  if (!hist_zeroed) NR_CHECK_HIP(hipMemsetAsync(hist, 0, (size_t)table_rows * sizeof(int32_t), stream));
   int grid = (Mmax + 255) / 256;
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(id_hist_kernel, dim3(grid), dim3(256), 0, stream, count, ids, table_rows, hist);
@@ -3363,13 +3365,13 @@ int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const i
 // Forward flavour: ws int32 [3*M + n + 4]; ws[2] = 1 when row 0 of the (bf16) table is not all zero -> every row live;
 // ws[4 + 3M + i] = bit mask of sequence i (L <= 32): bit t set = token t is live.
 int nr_launch_compact_rows_fwd(const int32_t* ids, int M, int n, int L, const void* table_row0, int cols, int32_t* ws,
-                               hipStream_t stream, int32_t* posmap) {
+                               hipStream_t stream, int32_t* posmap, int32_t* zero4) {
   NR_CHECK_ARG(ids != nullptr && ws != nullptr && M > 0 && table_row0 != nullptr && n * L == M, "compact_rows_fwd: bad arguments");
   NR_CHECK_HIP(hipMemsetAsync(ws, 0, 4 * sizeof(int32_t), stream));
   NrProfScope ps(stream, "compact_rows[M=%d]", M);
   const int rpw = L <= 32 ? (4096 / L) * L : 4096;       // whole sequences per workgroup when their token masks are wanted
   hipLaunchKernelGGL(compact_rows_fwd_kernel, dim3((M + rpw - 1) / rpw), dim3(256), 0, stream, ids, M, n, L, (const bf16_t*)table_row0, cols, ws,
-                     posmap, L <= 32 ? reinterpret_cast<uint32_t*>(ws + 4 + 3 * (size_t)M) : nullptr, rpw);
+                     posmap, L <= 32 ? reinterpret_cast<uint32_t*>(ws + 4 + 3 * (size_t)M) : nullptr, rpw, zero4);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -3871,9 +3873,9 @@ __global__ __launch_bounds__(256) void zero_unneeded_kernel(const int32_t* __res
 }
 }  // namespace
 // out: int32 [4 + n]: out[0] = count, out[4 ..] = the needed sequences; y rows of the others are zero-filled (row_bytes % 16 == 0)
-int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream, int reach) {
+int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, size_t seq_bytes, hipStream_t stream, int reach, bool zeroed) {
   NR_CHECK_ARG(flags != nullptr && out != nullptr && y != nullptr && seq_bytes % 16 == 0 && (((uintptr_t)y) & 15) == 0, "needed_list: bad arguments");
-  NR_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream));
+  if (!zeroed) NR_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream));     // (zeroed: an earlier kernel of the call cleared out[0..4))
   NrProfScope ps(stream, "needed_list[n=%d]", n);
   hipLaunchKernelGGL(needed_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, flags, n, out, out + 4);
   hipLaunchKernelGGL(zero_unneeded_kernel, dim3(n), dim3(256), 0, stream, flags, reinterpret_cast<uint4*>(y), (int)(seq_bytes / 16), n, reach);
@@ -3882,8 +3884,8 @@ int nr_launch_needed_list(const int32_t* flags, int n, int32_t* out, void* y, si
 }
 
 // out: int32 [4 + n]: out[0] = count, out[4 ..] = sequence numbers
-int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream, int reach) {
-  NR_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream));
+int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, int L, int32_t* out, hipStream_t stream, int reach, bool zeroed) {
+  if (!zeroed) NR_CHECK_HIP(hipMemsetAsync(out, 0, 4 * sizeof(int32_t), stream));
   hipLaunchKernelGGL(seq_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, title_nz, tmask, n, reach >= 0 ? reach : 32 / L + 2, out,
                      out + 4);
   NR_CHECK_LAUNCH();
@@ -3893,14 +3895,24 @@ int nr_launch_seq_list(const int32_t* title_nz, const uint32_t* tmask, int n, in
 // rows *count .. roundup32(*count) of a [Mmax, ld] bf16 buffer become zeros (compact row storage: the weight-gradient GEMM
 // contracts whole 32-row slabs of the live rows)
 namespace {
-__global__ __launch_bounds__(256) void zero_tail_rows_kernel(uint4* __restrict__ buf, int chunks, const int32_t* __restrict__ count, int Mmax) {
+// za / zb (optional): int32 regions cleared on the way -- counters and histograms of kernels that follow in the same call
+// (each used to be a hipMemsetAsync of its own, ~5 us apiece in a chain of dependent launches)
+__global__ __launch_bounds__(256) void zero_tail_rows_kernel(uint4* __restrict__ buf, int chunks, const int32_t* __restrict__ count, int Mmax,
+                                                             int32_t* __restrict__ za, int na, int32_t* __restrict__ zb, int nb) {
+  const int t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+  for (int i = t; i < na; i += stride) za[i] = 0;
+  for (int i = t; i < nb; i += stride) zb[i] = 0;
+  if (blockIdx.x != 0) return;
   const int n = *count, end = min(Mmax, (n + 31) / 32 * 32);
   for (int u = threadIdx.x; u < (end - n) * chunks; u += 256) buf[(size_t)n * chunks + u] = make_uint4(0, 0, 0, 0);
 }
 }  // namespace
-int nr_launch_zero_tail_rows(void* buf, int ld, const int32_t* count, int Mmax, hipStream_t stream) {
+int nr_launch_zero_tail_rows(void* buf, int ld, const int32_t* count, int Mmax, hipStream_t stream, int32_t* za, int na, int32_t* zb, int nb) {
   NR_CHECK_ARG(buf != nullptr && count != nullptr && ld % 8 == 0 && (((uintptr_t)buf) & 15) == 0, "zero_tail_rows: bad arguments");
-  hipLaunchKernelGGL(zero_tail_rows_kernel, dim3(1), dim3(256), 0, stream, (uint4*)buf, ld / 8, count, Mmax);
+  if (za == nullptr) na = 0;
+  if (zb == nullptr) nb = 0;
+  const int most = na > nb ? na : nb, grid = most > 4096 ? 16 : 1;
+  hipLaunchKernelGGL(zero_tail_rows_kernel, dim3(grid), dim3(256), 0, stream, (uint4*)buf, ld / 8, count, Mmax, za, na, zb, nb);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
