@@ -286,7 +286,7 @@ static int mhsa_rows(const nr_mhsa_desc* d, RowSrc* out) {
 // row_ws (int32): [0,4) counters | M live rows | M their ids | M padding rows | n per-sequence live-token masks |
 //                 slab scratch: n title flags, 4 counters, M/32 slab ids, 4 pad | sequence list: 4 counters, n entries
 struct MhsaWs {
-  size_t live_idx, live_ids, dead_idx, tmask, slab, seq, sort_idx, sort_ids, hist, pos, sort_k, dump, tn_scratch, tn_floats, total;   // offsets in int32 elements
+  size_t live_idx, live_ids, dead_idx, tmask, slab, seq, sort_idx, sort_ids, hist, cursor, pos, sort_k, dump, tn_scratch, tn_floats, total;   // offsets in int32 elements
 };
 // table_rows > 0 (gather source): room for the live rows sorted by token id (table-gradient scatter) and its histogram
 static MhsaWs mhsa_ws_layout(int n, int L, int table_rows, int N3 = 0, int Kp = 0) {
@@ -300,7 +300,8 @@ static MhsaWs mhsa_ws_layout(int n, int L, int table_rows, int N3 = 0, int Kp = 
   w.hist = w.sort_ids + (table_rows > 0 ? (M + 3) / 4 * 4 : 0);
   // compact row storage (gather source): position of every row in the live list | the id-sorted rows' positions in it | one
   // dump row of 3N <= 2048 elements (what an all-padding sequence's gradient stores hit)
-  w.pos = (w.hist + (table_rows > 0 ? (size_t)table_rows + 8 : 0) + 3) / 4 * 4;
+  w.cursor = w.hist + (table_rows > 0 ? (size_t)table_rows + 8 : 0);      // the scanned histogram (compact row storage: hist itself stays)
+  w.pos = (w.cursor + (table_rows > 0 ? (size_t)table_rows + 8 : 0) + 3) / 4 * 4;
   w.sort_k = w.pos + (table_rows > 0 ? (M + 3) / 4 * 4 : 0);
   w.dump = w.sort_k + (table_rows > 0 ? (M + 3) / 4 * 4 : 0);
   // partial tiles of the weight-gradient GEMM's splits (fp32; see nr_launch_gemm_tn_slabs): store + reduce instead of atomics
@@ -628,12 +629,13 @@ int nr_mhsa_fwd(const nr_mhsa_desc* d, void* qkv, void* y, nr_stream_t stream) {
     // compaction keeps every row and nothing changes.
     // (the compaction kernel also clears the counters of the "needed" list built further down: one memset less in the chain)
     if (compacting && (rc = nr_launch_compact_rows_fwd(d->ids, M, d->n, d->L, d->x, d->d_model, d->row_ws, s, cstore ? d->row_ws + W.pos : nullptr,
-                                                       d->row_ws + W.seq)))
+                                                       d->row_ws + W.seq, cstore ? d->row_ws + W.hist : nullptr, d->table_rows)))
       return rc;
     seq_hdr_zeroed = compacting;
     if (cstore) {
       NR_CHECK_ARG(nr_attn_pad_ok(d->dtype, d->L, d->d_head, qkv, y), "mhsa_fwd: qkv / y must be 8-byte aligned");
-      if ((rc = nr_launch_gather_live_rows(d->dtype, A, d->x_rows, d->ld_rows, M, Kp, d->row_ws, d->row_ws + W.live_idx, d->row_ws + W.live_ids, s)))
+      if ((rc = nr_launch_gather_live_rows(d->dtype, A, d->x_rows, d->ld_rows, M, Kp, d->row_ws, d->row_ws + W.live_idx, d->row_ws + W.live_ids, s,
+                                           d->row_ws + W.hist, d->table_rows)))       // (+ the id histogram for the backward's sort)
         return rc;
       A = dense_rows(d->x_rows, d->ld_rows, d->d_model);
       ep.row_count = d->row_ws; ep.row_idx = d->row_ws + W.live_idx; ep.row_ids = d->row_ws + W.live_ids;
@@ -719,9 +721,9 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
         slab_ws = ws + W.slab;
       }
       // rows count .. roundup32(count) of dqkv: the weight-gradient GEMM contracts whole 32-row slabs (x_c is zero there);
-      // the same launch clears the counters of the sequence list and the histogram of the id sort that follow
+      // the same launch clears the counters of the sequence list that follows
       int32_t* seq_ws = ws + W.seq;
-      if ((rc = nr_launch_zero_tail_rows(dqkv, 3 * N, ws, M, s, seq_ws, 4, ws + W.hist, d->table_rows))) return rc;
+      if ((rc = nr_launch_zero_tail_rows(dqkv, 3 * N, ws, M, s, seq_ws, 4))) return rc;
       // the walk leaves out the all-padding sequences with a zero gradient (nothing to store, nothing to add to db); slab
       // distances do not matter any more -- no slab is contracted -- so the list kernel runs with a zero reach
       if ((rc = nr_launch_seq_list(slab_ws, tmask, d->n, d->L, seq_ws, s, /*reach=*/0, /*zeroed=*/true))) return rc;
@@ -730,7 +732,7 @@ int nr_mhsa_bwd(const nr_mhsa_desc* d, const void* qkv, const void* dy, void* dq
         return rc;
       // table gradient: rows in token-id order, A rows through their live-list positions
       if ((rc = nr_launch_sort_rows_by_id(ws, ws + W.live_idx, ws + W.live_ids, M, d->table_rows, ws + W.hist, ws + W.sort_idx, ws + W.sort_ids, s,
-                                          ws + W.sort_k, /*hist_zeroed=*/true)))
+                                          ws + W.sort_k, /*histogram counted by the forward:*/ws + W.cursor)))
         return rc;
       EpiArgs ep = store_epi(dtable, d->d_model, NR_F32, nullptr, 0);
       ep.ids = d->ids; ep.ids_stride = 1; ep.Dtrue = d->d_model; ep.drop = nr_make_drop(d->p_in, d->seed_in);

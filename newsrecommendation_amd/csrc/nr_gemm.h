@@ -75,12 +75,14 @@ int nr_launch_compact_rows(const int32_t* ids, int ids_stride, int M, int32_t* w
 // hist int32 [table_rows + 8] scratch).  Order inside a group is arbitrary.
 // k_out (optional): position of each sorted row in the unsorted live list
 int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const int32_t* ids, int Mmax, int table_rows, int32_t* hist,
-                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream, int32_t* k_out = nullptr, bool hist_zeroed = false);
+                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream, int32_t* k_out = nullptr,
+                              int32_t* counted_cursor = nullptr);   // counted_cursor [table_rows]: hist is already counted (and stays intact)
 // forward flavour: ws int32 [3*M + n + 4] (adds ws[1] = dead count, ws[2] = "table row 0 is not zero", ws[4+2M ..] dead rows,
 // ws[4+3M ..] per-sequence live-token bit masks when L <= 32)
 // posmap (optional [M]): position of every row in the live list (-1: dead)
 int nr_launch_compact_rows_fwd(const int32_t* ids, int M, int n, int L, const void* table_row0, int cols, int32_t* ws,
-                               hipStream_t stream, int32_t* posmap = nullptr, int32_t* zero4 = nullptr);   // zero4: 4 more counters to clear
+                               hipStream_t stream, int32_t* posmap = nullptr, int32_t* zero4 = nullptr, int32_t* zhist = nullptr,
+                               int nhist = 0);   // zero4 / zhist [nhist]: more counters to clear
 // tmask (optional, with L): rows of sequences whose live-token mask is 0 are skipped (the attention kernels cover them)
 int nr_launch_bias_rows(void* C, int ldc, int N, const float* bias, const int32_t* rows, const int32_t* count, int max_rows,
                         const uint32_t* tmask, int L, hipStream_t stream);
@@ -118,6 +120,6 @@ int nr_launch_pool_fused_bwd(const void* x, int ldx, const void* e, int lde, con
                              const int32_t* nz, int n, int L, int N, int q, hipStream_t stream, int* grid_out, int dx_far_unwritten = 0);
 // live rows only, in live-list order (count / rows / ids of nr_launch_compact_rows_fwd), zero-filled to a multiple of 32 rows
 int nr_launch_gather_live_rows(int dtype, const RowSrc& A, void* out, int ldo, int Mmax, int K, const int32_t* count, const int32_t* rows,
-                               const int32_t* ids, hipStream_t stream);
+                               const int32_t* ids, hipStream_t stream, int32_t* hist = nullptr, int V = 0);   // hist [V]: occurrences per id, counted on the way
 int nr_launch_gemm_tn(int dtype, const void* dC, int ldc, const RowSrc& A, float* dW, int ldw, float* db,
                       int M, int N, int K, int Nstore, int Kstore, hipStream_t stream);

@@ -3043,8 +3043,12 @@ __global__ __launch_bounds__(256) void gather_title_kernel(RowSrc A, T* __restri
 // zero-filled (the weight-gradient GEMM contracts whole 32-row slabs).  Four independent (index -> table -> store) chains
 // per thread: the gather is latency bound, not bandwidth bound, with one (rows_materialize ran at 2.9 TB/s).
 template <typename T>
+// hist (optional, [V], cleared by the compaction kernel): occurrences per token id, counted by the thread that holds a row's
+// first chunk -- the backward's id sort then starts at its scan (the histogram pass was 14 us of dependent launch there; here
+// its atomics disappear under the row traffic)
 __global__ __launch_bounds__(256) void gather_live_rows_kernel(RowSrc A, T* __restrict__ out, int ldo, int K, const int32_t* __restrict__ count,
-                                                               const int32_t* __restrict__ rows, const int32_t* __restrict__ ids) {
+                                                               const int32_t* __restrict__ rows, const int32_t* __restrict__ ids,
+                                                               int32_t* __restrict__ hist, int V) {
   constexpr int CH = 16 / (int)sizeof(T), U = 4;
   const int cpr = K / CH, n = *count, nz = (n + 31) / 32 * 32;
   const uint32_t total = (uint32_t)nz * (uint32_t)cpr, stride = gridDim.x * 256u;
@@ -3067,6 +3071,7 @@ __global__ __launch_bounds__(256) void gather_live_rows_kernel(RowSrc A, T* __re
     for (int j = 0; j < U; ++j) {
       v[j].u = make_uint4(0, 0, 0, 0);
       if (row[j] >= 0) v[j].u = *reinterpret_cast<const uint4*>((const T*)A.base + (size_t)id[j] * A.ld + c[j]);
+      if (hist != nullptr && row[j] >= 0 && c[j] == 0 && (uint32_t)id[j] < (uint32_t)V) atomicAdd(hist + id[j], 1);
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -3170,7 +3175,7 @@ __global__ __launch_bounds__(256) void bias_rows_kernel(bf16_t* __restrict__ C, 
 __global__ __launch_bounds__(256) void compact_rows_fwd_kernel(const int32_t* __restrict__ ids, int M, int n, int L,
                                                                const bf16_t* __restrict__ row0, int cols, int32_t* __restrict__ ws,
                                                                int32_t* __restrict__ posmap, uint32_t* __restrict__ tmask, int rows_per_wg,
-                                                               int32_t* __restrict__ zero4) {
+                                                               int32_t* __restrict__ zero4, int32_t* __restrict__ zhist, int nhist) {
   constexpr int RPT = 16;
   __shared__ int wave_cnt[RPT][4];
   __shared__ int base, dbase;
@@ -3181,6 +3186,7 @@ __global__ __launch_bounds__(256) void compact_rows_fwd_kernel(const int32_t* __
   const bool keep_all = __syncthreads_or(nz) != 0;
   if (blockIdx.x == 0 && tid == 0) ws[2] = keep_all ? 1 : 0;
   if (zero4 != nullptr && blockIdx.x == 0 && tid < 4) zero4[tid] = 0;       // the counters of a list a LATER kernel of the call builds
+  for (int i = blockIdx.x * 256 + tid; i < nhist; i += gridDim.x * 256) zhist[i] = 0;   // ... and the id histogram the row gather fills
   const int r0 = blockIdx.x * rows_per_wg, r1 = min(M, r0 + rows_per_wg);
   int id[RPT];
   uint64_t bal[RPT];
@@ -3280,7 +3286,7 @@ __global__ __launch_bounds__(256) void id_hist_kernel(const int32_t* __restrict_
 // exclusive scan of hist[0 .. V) in place, by one workgroup (V is a vocabulary size: tens of thousands).  in_lds: the
 // whole histogram is staged in LDS by coalesced, independent loads (the strided per-thread runs over global memory were a
 // chain of dependent-latency loads: 30 us of the sort's 80)
-__global__ __launch_bounds__(1024) void id_scan_kernel(int32_t* __restrict__ hist, int V, int in_lds) {
+__global__ __launch_bounds__(1024) void id_scan_kernel(const int32_t* hist, int32_t* out, int V, int in_lds) {   // out may be hist itself
   __shared__ int sSum[1024];
   extern __shared__ __attribute__((aligned(16))) int sH[];
   const int tid = threadIdx.x, per = (V + 1023) / 1024, v0 = tid * per, v1 = min(V, v0 + per);
@@ -3318,11 +3324,11 @@ __global__ __launch_bounds__(1024) void id_scan_kernel(int32_t* __restrict__ his
       run += h;
     }
     __syncthreads();
-    for (int v = tid; v < V; v += 1024) hist[v] = sH[v];
+    for (int v = tid; v < V; v += 1024) out[v] = sH[v];
   } else {
     for (int v = v0; v < v1; ++v) {
       const int h = hist[v];
-      hist[v] = run;
+      out[v] = run;
       run += h;
     }
   }
@@ -3345,19 +3351,25 @@ __global__ __launch_bounds__(256) void id_scatter_kernel(const int32_t* __restri
 }  // namespace
 
 int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const int32_t* ids, int Mmax, int table_rows, int32_t* hist,
-                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream, int32_t* k_out, bool hist_zeroed) {
+                              int32_t* rows_out, int32_t* ids_out, hipStream_t stream, int32_t* k_out, int32_t* counted_cursor) {
   NR_CHECK_ARG(count && rows && ids && hist && rows_out && ids_out && Mmax > 0 && table_rows > 0, "sort_rows_by_id: bad arguments");
   NrProfScope ps(stream, "sort_rows_by_id[Mmax=%d,V=%d]", Mmax, table_rows);
-  if (!hist_zeroed) NR_CHECK_HIP(hipMemsetAsync(hist, 0, (size_t)table_rows * sizeof(int32_t), stream));
   int grid = (Mmax + 255) / 256;
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(id_hist_kernel, dim3(grid), dim3(256), 0, stream, count, ids, table_rows, hist);
+  // counted_cursor: `hist` already holds the histogram of exactly these ids (the forward's row gather counted them); it is left
+  // intact -- the call may be repeated -- and the scan goes into counted_cursor [table_rows]
+  int32_t* cursor = counted_cursor != nullptr ? counted_cursor : hist;
+  if (counted_cursor == nullptr) {
+    NR_CHECK_HIP(hipMemsetAsync(hist, 0, (size_t)table_rows * sizeof(int32_t), stream));
+    hipLaunchKernelGGL(id_hist_kernel, dim3(grid), dim3(256), 0, stream, count, ids, table_rows, hist);
+  }
   const int in_lds = table_rows <= 36 * 1024 ? 1 : 0;
   if (in_lds) {
     NR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(id_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 36 * 1024 * 4));
   }
-  hipLaunchKernelGGL(id_scan_kernel, dim3(1), dim3(1024), in_lds ? (size_t)((table_rows + 3) / 4) * 16 : 0, stream, hist, table_rows, in_lds);
-  hipLaunchKernelGGL(id_scatter_kernel, dim3(grid), dim3(256), 0, stream, count, rows, ids, table_rows, hist, rows_out, ids_out, k_out);
+  hipLaunchKernelGGL(id_scan_kernel, dim3(1), dim3(1024), in_lds ? (size_t)((table_rows + 3) / 4) * 16 : 0, stream, (const int32_t*)hist, cursor,
+                     table_rows, in_lds);
+  hipLaunchKernelGGL(id_scatter_kernel, dim3(grid), dim3(256), 0, stream, count, rows, ids, table_rows, cursor, rows_out, ids_out, k_out);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -3365,13 +3377,13 @@ int nr_launch_sort_rows_by_id(const int32_t* count, const int32_t* rows, const i
 // Forward flavour: ws int32 [3*M + n + 4]; ws[2] = 1 when row 0 of the (bf16) table is not all zero -> every row live;
 // ws[4 + 3M + i] = bit mask of sequence i (L <= 32): bit t set = token t is live.
 int nr_launch_compact_rows_fwd(const int32_t* ids, int M, int n, int L, const void* table_row0, int cols, int32_t* ws,
-                               hipStream_t stream, int32_t* posmap, int32_t* zero4) {
+                               hipStream_t stream, int32_t* posmap, int32_t* zero4, int32_t* zhist, int nhist) {
   NR_CHECK_ARG(ids != nullptr && ws != nullptr && M > 0 && table_row0 != nullptr && n * L == M, "compact_rows_fwd: bad arguments");
   NR_CHECK_HIP(hipMemsetAsync(ws, 0, 4 * sizeof(int32_t), stream));
   NrProfScope ps(stream, "compact_rows[M=%d]", M);
   const int rpw = L <= 32 ? (4096 / L) * L : 4096;       // whole sequences per workgroup when their token masks are wanted
   hipLaunchKernelGGL(compact_rows_fwd_kernel, dim3((M + rpw - 1) / rpw), dim3(256), 0, stream, ids, M, n, L, (const bf16_t*)table_row0, cols, ws,
-                     posmap, L <= 32 ? reinterpret_cast<uint32_t*>(ws + 4 + 3 * (size_t)M) : nullptr, rpw, zero4);
+                     posmap, L <= 32 ? reinterpret_cast<uint32_t*>(ws + 4 + 3 * (size_t)M) : nullptr, rpw, zero4, zhist, zhist ? nhist : 0);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
@@ -3518,7 +3530,7 @@ int nr_launch_pool_fused_bwd(const void* x, int ldx, const void* e, int lde, con
 }
 
 int nr_launch_gather_live_rows(int dtype, const RowSrc& A, void* out, int ldo, int Mmax, int K, const int32_t* count, const int32_t* rows,
-                               const int32_t* ids, hipStream_t stream) {
+                               const int32_t* ids, hipStream_t stream, int32_t* hist, int V) {
   const int ch = nr_chunk(dtype);
   NR_CHECK_ARG(A.kind == ROWS_GATHER && K % ch == 0 && ldo % ch == 0 && ldo >= K && A.ld >= K && count && rows && ids && out,
                "gather_live_rows: bad arguments");
@@ -3528,9 +3540,9 @@ int nr_launch_gather_live_rows(int dtype, const RowSrc& A, void* out, int ldo, i
   if (grid > 256 * 16) grid = 256 * 16;              // 16 workgroups of 4 waves per CU: 64 row chains in flight per CU
   if (grid < 1) grid = 1;
   if (dtype == NR_BF16)
-    hipLaunchKernelGGL(gather_live_rows_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, stream, A, (bf16_t*)out, ldo, K, count, rows, ids);
+    hipLaunchKernelGGL(gather_live_rows_kernel<bf16_t>, dim3((unsigned)grid), dim3(256), 0, stream, A, (bf16_t*)out, ldo, K, count, rows, ids, hist, V);
   else
-    hipLaunchKernelGGL(gather_live_rows_kernel<float>, dim3((unsigned)grid), dim3(256), 0, stream, A, (float*)out, ldo, K, count, rows, ids);
+    hipLaunchKernelGGL(gather_live_rows_kernel<float>, dim3((unsigned)grid), dim3(256), 0, stream, A, (float*)out, ldo, K, count, rows, ids, hist, V);
   NR_CHECK_LAUNCH();
   return NR_OK;
 }
