@@ -672,11 +672,23 @@ def run_train(a, device, rank, world, dist_on, model_name, dtype, dense=False, s
             _lib.prof_enable(3, only=dominant)
         else:
             _lib.prof_enable(2)                     # no warm-up to choose from: the launches over >= 65 536 rows
+    # A generation-2 pass of Python's cycle collector over this process's heap takes ~50 ms (measured: it landed in the first
+    # timed step of the --feed device run and made 20 steps read 4.9 instead of 3.0 ms): collect BEFORE the clock starts, as
+    # timeit does; the collector stays enabled.  NR_BENCH_STEP_TIMES=1 prints the host time of every enqueue.
+    import gc
+    gc.collect()
+    fence()
     t0 = time.perf_counter()
+    trace = [] if os.environ.get("NR_BENCH_STEP_TIMES") else None
     for i in range(steps):
         loss = step(warmup + i)
+        if trace is not None:
+            trace.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
+    if trace is not None and rank == 0:
+        print("host enqueue per step (ms):", [round(1e3 * (b - a), 2) for a, b in zip([t0] + trace[:-1], trace)],
+              "drain", round(1e3 * (t0 + dt - trace[-1]), 2), file=sys.stderr)
     prof = {}
     if prof_on:
         _lib.prof_enable(False)
