@@ -54,7 +54,8 @@ int nr_last_error(char* buf, size_t n);
  * configuration; the environment variable NR_<NAME> presets an option once per process.  nr_get_option returns
  * -1 for an unknown name.  Not thread-synchronised with calls in flight: set options between calls.              */
 /* sizeof of the descriptor structs as this library was compiled: out[0..3] = nr_mhsa_desc, nr_conv_desc, nr_pool_desc,
- * nr_linear_desc.  A binding compares them with its own layout at load time (ABI drift -> refuse to run).            */
+ * nr_linear_desc, and with n >= 6 also out[4..5] = nr_cast_job, nr_pack_job.  A binding compares them with its own layout at
+ * load time (ABI drift -> refuse to run).                                                                              */
 int nr_abi_sizes(size_t* out, int n);
 /* Deterministic mode.  Outputs that several workgroups add into (dW, db, dtable, dpad) are accumulated with fp32 atomics
  * by default, so their last bits depend on the arrival order.  With a scratch buffer registered here they are accumulated

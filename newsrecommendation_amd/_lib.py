@@ -165,10 +165,11 @@ def lib():
                     fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
                     fn.argtypes = argtypes
                     fn.restype = RESTYPES.get(name, C.c_int)
-                sizes = (C.c_size_t * 4)()
-                if L.nr_abi_sizes(sizes, 4) != 0 or list(sizes) != [C.sizeof(t) for t in (MhsaDesc, ConvDesc, PoolDesc, LinearDesc)]:
+                structs = (MhsaDesc, ConvDesc, PoolDesc, LinearDesc, CastJob, PackJob)
+                sizes = (C.c_size_t * len(structs))()
+                if L.nr_abi_sizes(sizes, len(structs)) != 0 or list(sizes) != [C.sizeof(t) for t in structs]:
                     raise RuntimeError(f"libnrhip.so descriptor layout {list(sizes)} differs from the ctypes binding "
-                                       f"{[C.sizeof(t) for t in (MhsaDesc, ConvDesc, PoolDesc, LinearDesc)]}: rebuild the library")
+                                       f"{[C.sizeof(t) for t in structs]}: rebuild the library")
                 _lib = L
     return _lib
 

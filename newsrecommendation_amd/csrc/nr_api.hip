@@ -432,6 +432,7 @@ int nr_last_error(char* buf, size_t n) {
 int nr_abi_sizes(size_t* out, int n) {
   NR_CHECK_ARG(out != nullptr && n >= 4, "abi_sizes: need room for 4 entries");
   out[0] = sizeof(nr_mhsa_desc); out[1] = sizeof(nr_conv_desc); out[2] = sizeof(nr_pool_desc); out[3] = sizeof(nr_linear_desc);
+  if (n >= 6) { out[4] = sizeof(nr_cast_job); out[5] = sizeof(nr_pack_job); }
   return NR_OK;
 }
 
