@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box from the repo root:  bash tools/collect_profiles.sh r03
+# Run on the GPU box from the repo root:  bash tools/collect_profiles.sh r03 [bench]
 # Writes profiles/<tag>_* summaries (bench lines, kernel stats, HBM traffic PMC with per-step totals, SQ counters).
 # Every rocprofv3 pass is its own run (--pmc is never combined with other trace domains); raw output stays in /tmp.
 set -u
@@ -12,6 +12,7 @@ python3 bench.py > profiles/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || 
 python3 bench.py --feed device --no-cpu-baseline --no-also > profiles/${TAG}_bench_feed_device.json 2>> gpurun_out/${TAG}_bench.err || echo feed failed
 python3 bench.py --deterministic --no-cpu-baseline --no-also > profiles/${TAG}_bench_deterministic.json 2>> gpurun_out/${TAG}_bench.err || echo det failed
 NR_NO_COMPACT_ROWS=1 NR_NO_POOL_FUSED=1 python3 bench.py --no-cpu-baseline --no-also > profiles/${TAG}_bench_round2_paths.json 2>> gpurun_out/${TAG}_bench.err || echo old-path failed
+if [ "${2:-all}" = "bench" ]; then mkdir -p gpurun_out/profiles_${TAG}; cp profiles/${TAG}_bench*.json gpurun_out/profiles_${TAG}/; exit 0; fi   # bench lines only
 echo "[2/5] kernel trace + stats"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also > /tmp/kt.log 2>&1 || echo kernel-trace failed
 f=$(find /tmp/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" profiles/${TAG}_kernel_stats.csv
