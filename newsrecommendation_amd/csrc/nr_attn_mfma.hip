@@ -642,7 +642,7 @@ __device__ __forceinline__ uint32_t sload_u32(const void* p) {
 // FULL: every head slot of a group is a real head (heads % AW == 0).  The slots beyond the L*AW*d/4 pieces of a panel then
 // WRAP onto real pieces (duplicates load / store the same bytes), so every thread issues the same number of memory
 // instructions per item and the compiler can count them (s_waitcnt vmcnt(N) instead of vmcnt(0)).
-template <int PT, bool FULL = false> __device__ __forceinline__ Pieces<PT> make_pieces(int tid, int L, int d, int nimg) {
+template <int PT, bool FULL = false> __device__ __forceinline__ Pieces<PT> make_pieces(int tid, int L, int d, int nimg, bool slack = true) {
   Pieces<PT> pc;
   const int pph = d >> 2, ppr = AW * pph;            // pieces per head row / per panel row
   const uint32_t inv_ppr = (65536 + ppr - 1) / ppr, inv_pph = (65536 + pph - 1) / pph;   // exact for p < 1024, divisors <= 40
@@ -655,7 +655,7 @@ template <int PT, bool FULL = false> __device__ __forceinline__ Pieces<PT> make_
     const int h = (int)(((uint32_t)q * inv_pph) >> 16), c = 4 * (q - h * pph);
     const bool ok = row < L;
     pc.rh[t] = (row & 31) | ((ok ? h : AW) << 8);     // head slot AW = never active
-    pc.lq[t] = (h * (nimg * IMG + HPAD) + hbank(h) + ioff(row & 31, c)) | ((4 * q) << 16);
+    pc.lq[t] = ((slack ? h * (nimg * IMG + HPAD) + hbank(h) : h * nimg * IMG) + ioff(row & 31, c)) | ((4 * q) << 16);
   }
   return pc;
 }
@@ -967,12 +967,16 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
   // product that contracts over the padded head dimension pairs a dirty operand with a clean one (K.Q^T, V.G^T), while
   // the token-contracting products meet exact zeros of P / dS / G in the padded rows.
   bf16_t* img0 = reinterpret_cast<bf16_t*>(smem);
-  constexpr int HS = IMG + HPAD, MS = AW * HS;            // head slot (image + bank-offset slack, see hoff) / matrix block
+  // SLIM (compact storage at 4 waves per SIMD): the workgroup must fit 40 KB of LDS -- no bank-offset slack between the head
+  // images (1-2 % of time, see HPAD), no softmax-statistics block (nothing reads it any more), 20-float bias-gradient rows
+  constexpr bool SLIM = CPT && OCC == 4;
+  constexpr int HS = IMG + (SLIM ? 0 : HPAD), MS = AW * HS;   // head slot (image + bank-offset slack, see hoff) / matrix block
+  constexpr int FW = SLIM ? (HAS_MASK ? 32 : 0) : 128;        // floats per wave behind the images: the key mask (+ legacy room)
   bf16_t *imQ = img0, *imV = img0 + MS, *imK = img0 + 2 * MS, *imG = img0 + 3 * MS;
-  const int wo = wid * HS + hbank(wid);
+  const int wo = wid * HS + (SLIM ? 0 : hbank(wid));
   bf16_t *sQ = imQ + wo, *sK = imK + wo, *sV = imV + wo, *sG = imG + wo;
-  float* sF = reinterpret_cast<float*>(img0 + (size_t)4 * MS) + wid * 128;
-  float *sMask = sF, *sM = sF + 32, *sInv = sF + 64, *sRd = sF + 96;
+  float* sF = reinterpret_cast<float*>(img0 + (size_t)4 * MS) + wid * FW;
+  float* sMask = sF;
   static_assert(!CPT || (FULL && SUB), "compact row storage rides on the per-row padding substitution");
   const int L = LC ? LC : a.L, d = DC ? DC : a.d, heads = HC ? HC : a.heads;
   const int N = heads * d, N3 = 3 * N;
@@ -981,21 +985,21 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
   bf16_t* dqkv = reinterpret_cast<bf16_t*>(a.dqkv);
   const int h2 = lane >> 5, li = lane & 31;
   const float c1 = a.scale * LOG2E;
-  const Pieces<PT> pc = make_pieces<PT, FULL>(tid, L, d, 1);    // per matrix the AW head images are adjacent
+  const Pieces<PT> pc = make_pieces<PT, FULL>(tid, L, d, 1, !SLIM);    // per matrix the AW head images are adjacent
   zero_images(img0, 4 * MS, tid);
-  bf16_t* sBias = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(img0 + (size_t)4 * MS) + AW * 128);   // SUB: bias [3N] as bf16
+  bf16_t* sBias = reinterpret_cast<bf16_t*>(reinterpret_cast<float*>(img0 + (size_t)4 * MS) + AW * FW);   // SUB: bias [3N] as bf16
   if (SUB)
     for (int i = tid; i < N3; i += AW * 64) sBias[i] = (bf16_t)a.bias[i];
 
   const int hgroups = (heads + AW - 1) / AW, stride = gridDim.x;
-  // CPT: behind the bias table -- [32] positions of the current item's rows | per wave 3 x [32] sums | the bias-gradient
-  // accumulators [hgroups][AW][3][32] (column c of head slot w of group hg of matrix Q / K / V)
+  // CPT: behind the bias table -- [32] positions of the current item's rows | per wave [32] column sums of dS | the
+  // bias-gradient accumulators [hgroups][AW][3][DBS] (column c of head slot w of group hg of matrix Q / K / V)
+  constexpr int CSW = SLIM ? 32 : 96, DBS = SLIM ? 20 : 32;
   int* sPos = reinterpret_cast<int*>(sBias + ((N3 + 7) / 8) * 8);
-  float* sCs = reinterpret_cast<float*>(sPos + 32) + wid * 96;      // per wave: column sums of dS | row sums of dS | row sums of P
-  float *sRs = sCs + 32, *sRho = sCs + 64;
-  float* sDb = reinterpret_cast<float*>(sPos + 32) + AW * 96;
+  float* sCs = reinterpret_cast<float*>(sPos + 32) + wid * CSW;
+  float* sDb = reinterpret_cast<float*>(sPos + 32) + AW * CSW;
   if (CPT)
-    for (int i = tid; i < hgroups * AW * 96; i += AW * 64) sDb[i] = 0.f;
+    for (int i = tid; i < hgroups * AW * 3 * DBS; i += AW * 64) sDb[i] = 0.f;
   int pos_next = 0;                                      // CPT: dqkv row of token (tid & 31) of the prefetched sequence
   bool gz_seq = false;                                   // CPT: the prefetcher's sequence has dy = 0 by contract (a.nzf): its rows are not trusted
   uint32_t tm_cur = 0;                                   // CPT: live-token mask of the CURRENT item's sequence
@@ -1181,17 +1185,17 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
       if (CPT && li == 31) {
         // lanes 31 / 63: the item's bias-gradient contribution, columns c = 8k + 4 h2 + e of this wave's head; only these two
         // lanes ever touch the wave's accumulator rows, so a plain read-modify-write is enough
-        float* acc = sDb + ((it.hg * AW + wid) * 3) * 32 + 4 * h2;
+        float* acc = sDb + ((it.hg * AW + wid) * 3) * DBS + 4 * h2;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           if (8 * k + 4 * h2 < d) {
-            f32x4 q4 = *reinterpret_cast<f32x4*>(acc + 8 * k), k4 = *reinterpret_cast<f32x4*>(acc + 32 + 8 * k),
-                  v4 = *reinterpret_cast<f32x4*>(acc + 64 + 8 * k);
+            f32x4 q4 = *reinterpret_cast<f32x4*>(acc + 8 * k), k4 = *reinterpret_cast<f32x4*>(acc + DBS + 8 * k),
+                  v4 = *reinterpret_cast<f32x4*>(acc + 2 * DBS + 8 * k);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { q4[e] += dq[4 * k + e]; k4[e] += dk[4 * k + e]; v4[e] += dv[4 * k + e]; }
             *reinterpret_cast<f32x4*>(acc + 8 * k) = q4;
-            *reinterpret_cast<f32x4*>(acc + 32 + 8 * k) = k4;
-            *reinterpret_cast<f32x4*>(acc + 64 + 8 * k) = v4;
+            *reinterpret_cast<f32x4*>(acc + DBS + 8 * k) = k4;
+            *reinterpret_cast<f32x4*>(acc + 2 * DBS + 8 * k) = v4;
           }
         }
       }
@@ -1250,8 +1254,8 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(OCC, OC
   if (CPT) {
     // this workgroup's share of the bias gradient: 3N fp32 atomics (4096 workgroups x 4.8 KB: ~15 us of the chip's atomic rate)
     // (plain fp32 atomics: the caller does not use compact storage in deterministic mode)
-    for (int i = tid; i < hgroups * AW * 96; i += AW * 64) {
-      const int c = i & 31, mat = (i >> 5) % 3, head = i / 96;                   // accumulator slot hg * AW + w = head
+    for (int i = tid; i < hgroups * AW * 3 * DBS; i += AW * 64) {
+      const int c = i % DBS, mat = (i / DBS) % 3, head = i / (3 * DBS);          // accumulator slot hg * AW + w = head
       if (c < d && head < heads) atomicAdd(a.db + mat * N + head * d + c, sDb[i]);
     }
   }
@@ -1745,8 +1749,14 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
   const bool p3 = a.L * a.d <= 768, sub = a.tmask != nullptr;
   const bool cpt = bwd && a.pos != nullptr;              // compact row storage + bias gradient (see bwd_kernel, CPT)
   const int hgroups = (a.heads + AW - 1) / AW;
-  const size_t smem_s = smem + (sub ? (size_t)((3 * a.N + 7) / 8) * 8 * sizeof(bf16_t) : 0) +
-                        (cpt ? (size_t)(32 + AW * 96 + hgroups * AW * 96) * sizeof(float) : 0);
+  size_t smem_s = smem + (sub ? (size_t)((3 * a.N + 7) / 8) * 8 * sizeof(bf16_t) : 0) +
+                  (cpt ? (size_t)(32 + AW * 96 + hgroups * AW * 96) * sizeof(float) : 0);
+  // the compact-storage kernel of the reference's title shape runs 4 workgroups per CU on a slimmer layout (bwd_kernel, SLIM)
+  const bool slim = bwd && cpt && a.heads % AW == 0 && a.L == 30 && a.d == 20 && a.heads == 20 && p3 && !nr_opt(NR_OPT_ATTN_GENERIC) &&
+                    !nr_opt(NR_OPT_ATTN_PRED) && !nr_opt(NR_OPT_ATTN_BWD_OCC4);
+  if (slim)
+    smem_s = (size_t)AW * (4 * IMG * sizeof(bf16_t) + (a.mask ? 32 : 0) * sizeof(float)) + (size_t)((3 * a.N + 7) / 8) * 8 * sizeof(bf16_t) +
+             (size_t)(32 + AW * 32 + hgroups * AW * 3 * 20) * sizeof(float);
   if (cpt && nr_opt(NR_OPT_ATTN_BWD_GRID) > 0) blocks = std::min<long>(blocks, nr_opt(NR_OPT_ATTN_BWD_GRID));
   auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(AW * 64), smem_s, stream, a); };
   // FULL: all head slots real and the store panels alias the images (d <= 21 in the backward): unpredicated memory
@@ -1759,7 +1769,8 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
     if (bwd && cpt) {
       // (launcher contract: FULL shape with per-row substitution, L <= 31)
       if constexpr (SB) {
-        if (title30) go(bwd_kernel<HM, 3, true, true, 30, 20, 20, 3, true>);
+        if (title30 && slim) go(bwd_kernel<HM, 3, true, true, 30, 20, 20, 4, true>);          // (NR_ATTN_BWD_OCC4=1: the 3-wave build)
+        else if (title30) go(bwd_kernel<HM, 3, true, true, 30, 20, 20, 3, true>);
         else p3 ? go(bwd_kernel<HM, 3, true, true, 0, 0, 0, 3, true>) : go(bwd_kernel<HM, 4, true, true, 0, 0, 0, 3, true>);
       }
     } else if (bwd) {
