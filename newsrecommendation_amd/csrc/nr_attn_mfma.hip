@@ -1287,18 +1287,37 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
   // source twice over): gather ids are fetched one sequence ahead, slices one item ahead.
   Slice t[2][3];
   int idr[2] = {0, 0};                                   // GATHER: table rows of this lane's tokens (row blocks 0 / 1) of the sequence being loaded
+  // GATHER with a key mask (eval: the clicked history is front-padded, src/dataset.py:17-24, and masked, user_log_mask): when the
+  // unmasked positions of a sequence are ONE run [shift, shift + len) the sequence is treated as that run alone -- tokens
+  // shift.. land in rows 0.., every key is valid, the output rows of the masked positions are zeros (the pooling that follows
+  // gives them weight 0, src/model/model_utils.py:28) -- and a run of <= 32 tokens needs ONE 32 x 32 tile where the padded
+  // sequence needed four.  Mathematically the same attention (the softmax maximum is taken over the valid keys only, the
+  // reference's + 1e-8 travels with it); any other mask pattern takes the general path.  *_n: the sequence being loaded.
+  int sh_n = 0, ln_n = L, sh_c = 0, ln_c = L;
+  bool gen_n = false, gen_c = false;
   auto load_ids = [&](long sb) {
     if (GATHER) {
       const size_t row0 = (size_t)sb * L;
+      sh_n = 0; ln_n = L; gen_n = false;
+      if (a.mask != nullptr) {
+        const float mv = lane < L ? a.mask[row0 + lane] : 0.f;
+        const unsigned long long bal = __ballot(mv != 0.f);
+        if (bal == 0) {
+          sh_n = L; ln_n = 0;                            // nothing valid: every output row is zero
+        } else {
+          const int s0 = __builtin_ctzll(bal), hi = 64 - __builtin_clzll(bal);
+          if (__popcll(bal) == hi - s0) { sh_n = s0; ln_n = hi - s0; } else gen_n = true;
+        }
+      }
       const int r = lane & 31;
-      idr[0] = r < L ? a.ids[row0 + r] : 0;
-      idr[1] = 32 + r < L ? a.ids[row0 + 32 + r] : 0;
+      idr[0] = r < ln_n ? a.ids[row0 + sh_n + r] : 0;
+      idr[1] = 32 + r < ln_n ? a.ids[row0 + sh_n + 32 + r] : 0;
     }
   };
   auto load = [&](long sb, int hgi) {
     const int hraw = hgi * AW + wid;
     const bool active = hraw < heads;
-    const int head = active ? hraw : 0, Lw = active ? L : 0;
+    const int head = active ? hraw : 0, Lw = active ? (GATHER ? ln_n : L) : 0;
     const size_t row0 = (size_t)sb * L;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -1329,7 +1348,10 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int hgi = 0; hgi < hgroups; ++hgi) {
       const int hraw = hgi * AW + wid;
       const bool active = hraw < heads;
-      const int head = active ? hraw : 0, Lw = active ? L : 0;
+      if (GATHER && hgi == 0) { sh_c = sh_n; ln_c = ln_n; gen_c = gen_n; }     // (the prefetch below moves *_n on to the next sequence)
+      const int Lc = GATHER ? ln_c : L;                  // tokens of this sequence that take part
+      const bool two = Lc > 32;                          // wave- and workgroup-uniform: the second row block is in use
+      const int head = active ? hraw : 0, Lw = active ? Lc : 0;
       const size_t row0 = (size_t)sb * L;
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb) {
@@ -1338,7 +1360,15 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         slice_put<false>(t[rb][1], Lr, d, sK + rb * IMG, lane, nodrop, 0, 0);
         slice_put<false>(t[rb][2], Lr, d, sV + rb * IMG, lane, nodrop, 0, 0);
       }
-      sMask[lane] = (lane < Lw) ? (a.mask ? a.mask[row0 + lane] : 1.f) : 0.f;
+      sMask[lane] = (lane < Lw) ? ((a.mask && (!GATHER || gen_c)) ? a.mask[row0 + lane] : 1.f) : 0.f;
+      if (GATHER && Lc < L) {
+        // output rows of the masked positions (in front of and behind the run): zeros, this head group's columns
+        const int hcols = min(AW, heads - hgi * AW) * d, ppr = hcols >> 2, nz = (L - Lc) * ppr;
+        for (int u = threadIdx.x; u < nz; u += AW * 64) {
+          const int i = u / ppr, c = (u - i * ppr) * 4, row = i < sh_c ? i : i + Lc;
+          *reinterpret_cast<bf16x4*>(y + (row0 + row) * N + hgi * AW * d + c) = (bf16x4){(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        }
+      }
       __syncthreads();
       // this lane's 16 + 16 key-mask values (0 beyond L), once per item instead of once per query block and element
       float mk0[16], mk1[16];
@@ -1352,12 +1382,12 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         load(sb + gridDim.x, 0);
       }
 #pragma unroll 1
-      for (int qb = 0; qb < 2; ++qb) {
+      for (int qb = 0; qb < (two ? 2 : 1); ++qb) {
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
         mm_rr(s0, sK, sQ + qb * IMG, lane);         // keys 0..31   x queries of block qb
-        mm_rr(s1, sK + IMG, sQ + qb * IMG, lane);   // keys 32..63
+        if (two) mm_rr(s1, sK + IMG, sQ + qb * IMG, lane);   // keys 32..63
         // softmax over the keys of one query (a lane pair): exp(scale*s - m) = exp2(s*c - m*c), c = scale*log2(e): the raw
         // scores go through one fma + v_exp_f32; keys >= L have mask 0 (the key block 0 is always complete: L > 32)
         const float c2 = a.scale * 1.44269504088896341f;
@@ -1365,7 +1395,9 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           mr = fmaxf(mr, s0[r]);
-          if (32 + rowof(r, h2) < L) mr = fmaxf(mr, s1[r]);
+          // GATHER: the run length is a run-time value; key rows behind it are ZERO rows of the images (score exactly 0), which
+          // may take part in the maximum -- any finite m gives the same softmax -- so no per-row predicate is needed
+          if (GATHER ? two : (32 + rowof(r, h2) < L)) mr = fmaxf(mr, s1[r]);
         }
         mr = fmaxf(mr, __shfl_xor(mr, 32, 64));
         const float m = mr * a.scale, mc = -mr * c2;
@@ -1373,9 +1405,16 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float e0 = __builtin_amdgcn_exp2f(fmaf(s0[r], c2, mc)) * mk0[r];
-          const float e1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, mc)) * mk1[r];
-          s0[r] = e0; s1[r] = e1;
-          sum += e0 + e1;
+          s0[r] = e0;
+          sum += e0;
+        }
+        if (two) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e1 = __builtin_amdgcn_exp2f(fmaf(s1[r], c2, mc)) * mk1[r];
+            s1[r] = e1;
+            sum += e1;
+          }
         }
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.f / (sum + 1e-8f * __expf(-m));
@@ -1385,11 +1424,11 @@ __global__ __launch_bounds__(AW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
         mm_xt(ctx, s0, sV, lane);
-        mm_xt(ctx, s1, sV + IMG, lane);
+        if (two) mm_xt(ctx, s1, sV + IMG, lane);
         __syncthreads();
         acc_to_img_t(ctx, 1.f, sO, lane);
         __syncthreads();
-        const size_t r0 = row0 + 32 * qb;
+        const size_t r0 = row0 + (GATHER ? sh_c : 0) + 32 * qb;
         img_t_to_global<true>(sO, y + r0 * N + head * d, N, clampL(Lw, qb), d, lane, a.drop, (uint32_t)(r0 * N + head * d), (uint32_t)N);
       }
       __syncthreads();

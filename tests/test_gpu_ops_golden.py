@@ -147,9 +147,13 @@ def test_eval_projected_table_shortcut_gives_the_same_news_vectors():
     assert float((got2 - ref2).abs().max()) <= 2e-3 * float(ref2.abs().max())   # ... and the shortcut followed it
 
 
-def test_user_encoder_forward_indexed_equals_gather_then_forward():
+@pytest.mark.parametrize("pattern", ["front", "back", "middle", "holes", "full"])
+def test_user_encoder_forward_indexed_equals_gather_then_forward(pattern):
     """Eval: UserEncoder.forward_indexed(news_table, idx, mask) (projected news-vector table + gathering attention, L = 50) vs
-    the reference call shape user_encoder(news_table[idx], mask) -- bf16 output rounding only."""
+    the reference call shape user_encoder(news_table[idx], mask) -- bf16 output rounding only.  The gathering kernel treats a
+    sequence whose unmasked positions form ONE run as that run alone (one 32 x 32 tile for a run of <= 32 clicks); `front` is
+    the reference's own padding (src/dataset.py:17-24), the other patterns drive the back-padded / interior-run / general
+    (masks with holes) / unmasked paths through the same comparison."""
     import bench
     from newsrecommendation_amd.model import NRMS
     args = bench.make_args("bf16")
@@ -161,7 +165,22 @@ def test_user_encoder_forward_indexed_equals_gather_then_forward():
     news = (torch.randn(5000, 400, generator=g) * 0.3).cuda()
     idx = torch.randint(0, 5000, (300, 50), generator=g, dtype=torch.int32).cuda()
     hl = torch.randint(0, 51, (300,), generator=g)
-    mask = (torch.arange(50)[None, :] >= (50 - hl)[:, None]).float().cuda()
+    hl[:8] = torch.tensor([0, 1, 18, 31, 32, 33, 49, 50])                                # the tile boundaries
+    pos = torch.arange(50)[None, :]
+    if pattern == "front":
+        mask = pos >= (50 - hl)[:, None]
+    elif pattern == "back":
+        mask = pos < hl[:, None]
+    elif pattern == "middle":
+        start = (torch.rand(300, generator=g) * (51 - hl)).long()
+        mask = (pos >= start[:, None]) & (pos < (start + hl)[:, None])
+    elif pattern == "holes":
+        mask = (pos >= (50 - hl)[:, None]) & (torch.rand(300, 50, generator=g) < 0.7)
+    else:
+        mask = torch.ones(300, 50, dtype=torch.bool)
+        hl[:] = 50
+    hl = mask.sum(1)
+    mask = mask.float().cuda()
     with torch.no_grad():
         ref = m.user_encoder(ops.embed_gather(news, idx), mask)
         got = m.user_encoder.forward_indexed(news, idx, mask)
