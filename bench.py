@@ -465,8 +465,16 @@ def run_eval(a, args, device, rank, world, dist_on, steps=None, warmup=None, cpu
     hist = rnd.randint(1, a.eval_news + 1, (n, 50)).astype(np.int32)
     mask = (np.arange(50)[None, :] >= (50 - hl)[:, None]).astype(np.float32)
     hist[mask == 0] = 0
-    sh = ArrayShard(n, hist=hist, mask=mask, cand=rnd.randint(1, a.eval_news + 1, off[-1]).astype(np.int32),
-                    label=(rnd.rand(off[-1]) < 0.1).astype(np.int32), offsets=off)
+    cand_np, label_np = rnd.randint(1, a.eval_news + 1, off[-1]).astype(np.int32), (rnd.rand(off[-1]) < 0.1).astype(np.int32)
+    if getattr(a, "eval_feed", "resident") == "resident":
+        # inputs resident in HBM when the clock starts, as for the training lines (the index arrays of the shard and the corpus:
+        # 90 MB; `--eval-feed host` re-uploads them from pageable numpy arrays in every pass, as a one-shot evaluation does)
+        dev_t = lambda x: torch.as_tensor(x, device=device)
+        sh = ArrayShard(n, hist=dev_t(hist), mask=dev_t(mask), cand=dev_t(cand_np), label=dev_t(label_np), offsets=off)
+        comb_in = dev_t(comb)
+    else:
+        sh = ArrayShard(n, hist=hist, mask=mask, cand=cand_np, label=label_np, offsets=off)
+        comb_in = comb
 
     def fence():
         if dist_on:
@@ -478,7 +486,7 @@ def run_eval(a, args, device, rank, world, dist_on, steps=None, warmup=None, cpu
     nv_keep = None
 
     def one_pass():
-        nv = TR.encode_news(model, comb, a.eval_batch, device, shard_over_ranks=dist_on)
+        nv = TR.encode_news(model, comb_in, a.eval_batch, device, shard_over_ranks=dist_on)
         scores, sums = TR.score_shard(model, nv, sh, a.eval_batch, device)
         return sums
 
@@ -512,6 +520,7 @@ def run_eval(a, args, device, rank, world, dist_on, steps=None, warmup=None, cpu
            "config": {"workload": f"NRMS eval: encode {a.eval_news} news (sharded over ranks) + score {n} impressions per GPU, candidates ~U[2,100], "
                                   "history 50, user_log_mask=True; AUC/MRR/nDCG on the device",
                       "news": a.eval_news, "impressions_per_gpu": n, "candidates": int(off[-1]), "eval_batch": a.eval_batch, "parallelism": f"dp{world}",
+                      "feed": getattr(a, "eval_feed", "resident"),
                       "scored_impressions": int(sums[0]), "mean_auc": round(sums[1] / max(sums[0], 1), 4)}}
     out["roofline"] = roofline_of(prof, a.dtype, struct)
     if prof:
@@ -806,6 +815,8 @@ def main():
     ap.add_argument("--eval-news", type=int, default=100000)
     ap.add_argument("--eval-impressions", type=int, default=125000, help="impressions per GPU (1M over 8 GPUs)")
     ap.add_argument("--eval-batch", type=int, default=2048)
+    ap.add_argument("--eval-feed", default="resident", choices=["resident", "host"],
+                    help="eval: index arrays resident on the device before the clock starts (default), or uploaded from host arrays in every pass")
     ap.add_argument("--no-also", action="store_true",
                     help="headline only: skip the other BASELINE configs (NAML, eval, dense batch, fp32) that the default 1-GPU "
                          "run measures in the same process and attaches under `also`")

@@ -1820,7 +1820,10 @@ int launch(bool bwd, const AttnMArgs& a, hipStream_t stream) {
       else p3 ? go(bwd_kernel<HM, 3, SB>) : go(bwd_kernel<HM, 4, SB>);
     } else if (!SB && a.ids != nullptr) {
       // eval's title-level gather: the specialised, unpredicated instantiation for the reference's default shape too
+      // (32 x 20 x 20: eval's short histories -- the last 32 clicks of a front-padded history, train.score_shard)
+      const bool user32 = full && p3 && a.L == 32 && a.d == 20 && a.heads == 20 && !nr_opt(NR_OPT_ATTN_GENERIC);
       if (title30) go(fwd_kernel<HM, 3, false, true, true, 30, 20, 20>);
+      else if (user32) go(fwd_kernel<HM, 3, false, true, true, 32, 20, 20>);
       else p3 ? go(fwd_kernel<HM, 3, false, true>) : go(fwd_kernel<HM, 4, false, true>);
     } else if (title30) {
       go(fwd_kernel<HM, 3, SB, false, true, 30, 20, 20>);

@@ -193,7 +193,8 @@ def encode_news(model, news_combined, batch_size, device, shard_over_ranks=False
     """Full-corpus encode (src/main.py:185-198); the [N+1, news_dim] table stays on the device.  With
     `shard_over_ranks` every rank encodes a contiguous 1/world slice and the slices are all-gathered --
     the reference encodes the whole corpus on every rank."""
-    ids = torch.as_tensor(np.asarray(news_combined), dtype=torch.int32)
+    # (a tensor that already lives on the device is taken as it is: the slices below are views, `.to(device)` a no-op)
+    ids = news_combined.to(torch.int32) if torch.is_tensor(news_combined) else torch.as_tensor(np.asarray(news_combined), dtype=torch.int32)
     n = ids.shape[0]
     batch_size = max(int(batch_size), 16384)                   # the encoder is row-wise: bigger chunks, same vectors, fewer launches
     world = parallel.world_size() if shard_over_ranks else 1
@@ -212,6 +213,22 @@ def encode_news(model, news_combined, batch_size, device, shard_over_ranks=False
     return torch.cat(parts, dim=0)[:n]
 
 
+def _short_history_split(shard, H):
+    """[(impressions whose first H - 32 history slots are all masked, H - 32), (the others, 0)] as index arrays; part of the
+    shard's preparation (numpy over its mask array), kept on the shard object."""
+    cached = getattr(shard, "_nr_short_split", None)
+    if cached is None or cached[0] != H:
+        m = shard.mask
+        m = m.detach().cpu().numpy() if torch.is_tensor(m) else np.asarray(m)
+        short = ~(m[:, :H - 32] != 0).any(axis=1)
+        cached = (H, [(np.nonzero(short)[0].astype(np.int64), H - 32), (np.nonzero(~short)[0].astype(np.int64), 0)], {})
+        try:
+            shard._nr_short_split = cached
+        except AttributeError:
+            pass
+    return cached[1], cached[2]
+
+
 @torch.no_grad()
 def score_shard(model, news_vecs, shard: IndexedTestShard, batch_size, device):
     """Rows a13 + f2 on the device: user vectors of every impression of the shard (history vectors gathered from the
@@ -226,13 +243,33 @@ def score_shard(model, news_vecs, shard: IndexedTestShard, batch_size, device):
     code = ops.dtype_code(getattr(margs, "compute_dtype", "fp32")) if getattr(margs, "user_log_mask", False) else ops.NR_F32
     batch_size = max(int(batch_size), 8192)                    # the user encoder is row-wise: bigger chunks, same vectors
     indexed = getattr(model.user_encoder, "forward_indexed", None)                 # history as indices into the vector table
-    for a in range(0, n, batch_size):
-        b = min(n, a + batch_size)
-        if indexed is not None:
-            user[a:b] = indexed(news_vecs, hist[a:b], mask[a:b])
-        else:
-            log_vecs = ops.embed_gather(news_vecs, hist[a:b], code)                   # [B, H, news_dim], device gather
-            user[a:b] = model.user_encoder(log_vecs, mask[a:b])                       # src/main.py:247
+    H = hist.shape[1] if hist.dim() == 2 else 0
+    if indexed is not None and getattr(margs, "user_log_mask", False) and H > 32 and n > 0:
+        # A masked slot contributes nothing to the masked user encoder (attention keys with weight 0, pooling weight 0:
+        # src/model/model_utils.py:28,51), so it can simply be left out.  Histories are front-padded (src/dataset.py:17-24): a
+        # user whose first H - 32 slots are all masked is encoded from the LAST 32 slots alone -- one 32 x 32 attention tile per
+        # head through the title-shape kernel (2.5 x the item rate of the 64-row kernel) and 32 instead of H pooling rows.  The
+        # split is made on the host from the shard's own mask array (no device synchronisation); same vectors.
+        groups, on_device = _short_history_split(shard, H)
+        for g, (idx_np, off) in enumerate(groups):
+            if len(idx_np) == 0:
+                continue
+            sel = on_device.get((g, str(device)))
+            if sel is None:
+                sel = on_device[(g, str(device))] = torch.as_tensor(idx_np, device=device)
+            h_g = hist.index_select(0, sel)[:, off:].contiguous()
+            m_g = mask.index_select(0, sel)[:, off:].contiguous()
+            for a in range(0, len(idx_np), batch_size):
+                b = min(len(idx_np), a + batch_size)
+                user.index_copy_(0, sel[a:b], indexed(news_vecs, h_g[a:b], m_g[a:b]).float())
+    else:
+        for a in range(0, n, batch_size):
+            b = min(n, a + batch_size)
+            if indexed is not None:
+                user[a:b] = indexed(news_vecs, hist[a:b], mask[a:b])
+            else:
+                log_vecs = ops.embed_gather(news_vecs, hist[a:b], code)               # [B, H, news_dim], device gather
+                user[a:b] = model.user_encoder(log_vecs, mask[a:b])                   # src/main.py:247
     offsets = torch.as_tensor(shard.offsets, device=device)
     counts = shard.offsets[1:] - shard.offsets[:-1]
     imp_of = torch.repeat_interleave(torch.arange(n, dtype=torch.int32, device=device), torch.as_tensor(counts, device=device).long())

@@ -187,3 +187,10 @@ def test_user_encoder_forward_indexed_equals_gather_then_forward(pattern):
     assert ref.shape == got.shape == (300, 400)
     assert float((got - ref).abs().max()) <= 3e-3 * float(ref.abs().max()) + 1e-4, float((got - ref).abs().max())
     assert float(got[hl == 0].abs().max()) == 0.0 if bool((hl == 0).any()) else True     # empty history -> exactly 0
+    if pattern == "front":
+        # what train.score_shard does with such users: the last 32 slots alone (the 18 masked ones in front left out) through
+        # the 32-row kernel -- same user vectors
+        short = (hl <= 32).cuda()
+        with torch.no_grad():
+            got32 = m.user_encoder.forward_indexed(news, idx[short][:, 18:].contiguous(), mask[short][:, 18:].contiguous())
+        assert float((got32 - ref[short]).abs().max()) <= 3e-3 * float(ref.abs().max()) + 1e-4
