@@ -697,7 +697,8 @@ class SplitRowsFunction(Function):
         ctx.n_a, ctx.arena = int(n_a), None
         a, b = x[:n_a], x[n_a:]
         _grad_out.clear()
-        if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2 and 0 < n_a < x.shape[0]:
+        if (ctx.needs_input_grad[0] and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+                and 0 < n_a < x.shape[0]):
             ctx.arena = torch.empty_like(x)
             _grad_out[(a.data_ptr(), a.numel())] = ctx.arena[:n_a]
             _grad_out[(b.data_ptr(), b.numel())] = ctx.arena[n_a:]
