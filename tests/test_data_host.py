@@ -171,3 +171,23 @@ def test_bf16_shards_round_trip_and_title_table_state_dict(tmp_path):
         m.news_encoder.title_embeddings.packed(1)
     args.freeze_embedding = False                                  # trainable: the reference's nn.Embedding, as before
     assert isinstance(NAML.Model(args, emb, 0, 0).news_encoder.title_embeddings, torch.nn.Embedding)
+
+
+def test_short_history_split_partitions_a_shard_by_its_own_mask():
+    """`train._short_history_split`: impressions whose first H - 32 history slots are all masked (front padding,
+    src/dataset.py:17-24) form the group that is encoded from the last 32 slots alone; the partition is exact, cached on the
+    shard object, and keyed by H."""
+    from types import SimpleNamespace
+    from newsrecommendation_amd import train as TR
+    H = 50
+    hl = np.array([0, 1, 18, 31, 32, 33, 49, 50, 7, 40])
+    mask = (np.arange(H)[None, :] >= (H - hl)[:, None]).astype(np.float32)
+    mask[8, 3] = 1.0                                      # a stray unmasked slot in front: not a short history
+    shard = SimpleNamespace(mask=mask)
+    groups, cache = TR._short_history_split(shard, H)
+    (short, off_s), (long_, off_l) = groups
+    assert off_s == H - 32 and off_l == 0
+    assert short.tolist() == [0, 1, 2, 3, 4] and long_.tolist() == [5, 6, 7, 8, 9]
+    assert sorted(short.tolist() + long_.tolist()) == list(range(10))
+    assert TR._short_history_split(shard, H)[0] is groups and cache == {}          # cached on the shard
+    assert TR._short_history_split(shard, 40)[0] is not groups                     # another H: recomputed
